@@ -1,0 +1,269 @@
+"""ctypes doorway onto oracle/libnuslam_oracle.so (the CPU checker) and, where it exists,
+oracle/_ref/librigid2d_ref.so (the reference's own rigid2d + DiffDrive, compiled from /root/reference).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libnuslam_oracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "librigid2d_ref.so")
+
+ORC_DENSE, ORC_STRUCTURED = 0, 1
+ORC_OK, ORC_E_ARG, ORC_E_BOUNDS, ORC_E_SINGULAR = 0, 1, 2, 3
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def build_oracle(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present). Building the checker is not using it."""
+    if force or not os.path.exists(ORACLE_SO) or (
+            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "nuslam_oracle.c"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/rigid2d/src") and not os.path.exists(REF_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_normalize_angle.restype = C.c_double
+        L.orc_normalize_angle.argtypes = [C.c_double]
+        L.orc_transform_twist.argtypes = [_dp, _dp, _dp]
+        L.orc_integrate_twist.argtypes = [_dp, _dp]
+        L.orc_dd_convert_twist.argtypes = [_dp, _dp, _dp]
+        L.orc_dd_get_twist.argtypes = [_dp, C.c_double, C.c_double, _dp]
+        L.orc_dd_step.argtypes = [_dp, C.c_double, C.c_double]
+        L.orc_cartesian2polar.argtypes = [C.c_double, C.c_double, _dp]
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [_dp, _dp, C.c_int, _dp, _dp]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_get_threads.restype = C.c_int
+        L.orc_predict.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.orc_predict_dense.argtypes = [C.c_void_p, _dp]
+        L.orc_measurement.argtypes = [_dp, C.c_int, _dp]
+        L.orc_jacobian.argtypes = [_dp, C.c_int, C.c_int, _dp]
+        L.orc_associate.argtypes = [C.c_void_p, C.c_double, C.c_double, _ip, _dp]
+        L.orc_init_landmark.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.orc_update.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int]
+        L.orc_tick.argtypes = [C.c_void_p, _dp, C.c_double, C.c_double, _dp, C.c_int, _dp, _dp, _ip, C.c_int, _ip]
+        for f in (L.orc_len, L.orc_n, L.orc_seen):
+            f.argtypes = [C.c_void_p]
+            f.restype = C.c_int
+        L.orc_set_seen.argtypes = [C.c_void_p, C.c_int]
+        L.orc_state.argtypes = [C.c_void_p]
+        L.orc_state.restype = _dp
+        L.orc_cov.argtypes = [C.c_void_p]
+        L.orc_cov.restype = _dp
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    def __init__(self, code):
+        super().__init__("oracle status %d" % code)
+        self.code = code
+
+
+def _chk(rc):
+    if rc != ORC_OK:
+        raise OracleError(rc)
+
+
+class OracleEKF:
+    """slam_library::ExtendedKalman as restated by the oracle. Matrices are column-major (Fortran order)."""
+
+    def __init__(self, robot, map_state, Q, R, mode=ORC_DENSE):
+        L = lib()
+        robot = np.ascontiguousarray(robot, dtype=np.float64)
+        map_state = np.ascontiguousarray(map_state, dtype=np.float64)
+        Qc = np.asfortranarray(np.asarray(Q, dtype=np.float64).reshape(3, 3))
+        Rc = np.asfortranarray(np.asarray(R, dtype=np.float64).reshape(2, 2))
+        n = map_state.size // 2
+        self._h = L.orc_create(_p(robot), _p(map_state) if map_state.size else None, n,
+                               Qc.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp))
+        if not self._h:
+            raise MemoryError("orc_create")
+        self.n = n
+        self.len = 3 + 2 * n
+        L.orc_set_mode(self._h, mode)
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, mode):
+        lib().orc_set_mode(self._h, mode)
+
+    @property
+    def state(self):
+        return np.ctypeslib.as_array(lib().orc_state(self._h), shape=(self.len,))
+
+    @property
+    def cov(self):
+        """Live view, shape (len, len), cov[i, j] = P(i, j)."""
+        flat = np.ctypeslib.as_array(lib().orc_cov(self._h), shape=(self.len * self.len,))
+        return flat.reshape((self.len, self.len), order="F")
+
+    @property
+    def seen(self):
+        return lib().orc_seen(self._h)
+
+    @seen.setter
+    def seen(self, v):
+        lib().orc_set_seen(self._h, int(v))
+
+    def restore(self, state, cov, seen):
+        self.state[:] = state
+        self.cov[:, :] = cov
+        self.seen = seen
+
+    def predict(self, dth, dx, dy=0.0):
+        lib().orc_predict(self._h, dth, dx, dy)
+
+    def predict_dense(self, F):
+        Fc = np.asfortranarray(F, dtype=np.float64)
+        _chk(lib().orc_predict_dense(self._h, Fc.ctypes.data_as(_dp)))
+
+    def update(self, r, phi, idx):
+        _chk(lib().orc_update(self._h, r, phi, idx))
+
+    def init_landmark(self, r, phi, idx):
+        _chk(lib().orc_init_landmark(self._h, r, phi, idx))
+
+    def associate(self, r, phi, want_d=False):
+        out = C.c_int(0)
+        d = np.full(max(self.seen, 1), np.nan)
+        _chk(lib().orc_associate(self._h, r, phi, C.byref(out), _p(d)))
+        return (out.value, d) if want_d else out.value
+
+    def tick(self, tw=None, dd=None, thL=0.0, thR=0.0, mx=(), my=(), known_ids=None, total_landmarks=None):
+        mx = np.ascontiguousarray(mx, dtype=np.float64)
+        my = np.ascontiguousarray(my, dtype=np.float64)
+        m = mx.size
+        ids_out = np.zeros(max(m, 1), dtype=np.int32)
+        kid = None
+        if known_ids is not None:
+            kid = np.ascontiguousarray(known_ids, dtype=np.int32)
+        twp = None
+        if tw is not None:
+            twa = np.ascontiguousarray(tw, dtype=np.float64)
+            twp = _p(twa)
+        _chk(lib().orc_tick(self._h, _p(dd) if dd is not None else None, thL, thR, twp, m,
+                            _p(mx), _p(my), kid.ctypes.data_as(_ip) if kid is not None else None,
+                            self.n if total_landmarks is None else total_landmarks,
+                            ids_out.ctypes.data_as(_ip)))
+        return ids_out[:m].copy()
+
+
+def measurement(state, j):
+    s = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.zeros(2)
+    lib().orc_measurement(_p(s), j, _p(out))
+    return out
+
+
+def jacobian(state, j):
+    s = np.ascontiguousarray(state, dtype=np.float64)
+    H = np.zeros((2, s.size), order="F")
+    lib().orc_jacobian(_p(s), s.size, j, H.ctypes.data_as(_dp))
+    return H
+
+
+def cartesian2polar(x, y):
+    out = np.zeros(2)
+    lib().orc_cartesian2polar(x, y, _p(out))
+    return out
+
+
+def normalize_angle(a):
+    return lib().orc_normalize_angle(a)
+
+
+def integrate_twist(tw):
+    tw = np.ascontiguousarray(tw, dtype=np.float64)
+    T = np.zeros(4)
+    lib().orc_integrate_twist(_p(tw), _p(T))
+    return T
+
+
+def transform_twist(T, tw):
+    T = np.ascontiguousarray(T, dtype=np.float64)
+    tw = np.ascontiguousarray(tw, dtype=np.float64)
+    out = np.zeros(3)
+    lib().orc_transform_twist(_p(T), _p(tw), _p(out))
+    return out
+
+
+def dd_new(base, rad, x=0.0, y=0.0, th=0.0, thL=0.0, thR=0.0):
+    return np.array([base, rad, x, y, th, thL, thR], dtype=np.float64)
+
+
+def dd_get_twist(dd, thL, thR):
+    out = np.zeros(3)
+    lib().orc_dd_get_twist(_p(dd), thL, thR, _p(out))
+    return out
+
+
+def dd_step(dd, thL, thR):
+    lib().orc_dd_step(_p(dd), thL, thR)
+    return dd
+
+
+def dd_convert_twist(dd, tw):
+    tw = np.ascontiguousarray(tw, dtype=np.float64)
+    out = np.zeros(2)
+    lib().orc_dd_convert_twist(_p(dd), _p(tw), _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- the real reference (rigid2d only)
+_ref = None
+
+
+def ref_available():
+    if not os.path.exists(REF_SO):
+        try:
+            build_oracle()
+        except Exception:
+            pass
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        R = C.CDLL(REF_SO)
+        R.ref_normalize_angle.restype = C.c_double
+        R.ref_normalize_angle.argtypes = [C.c_double]
+        R.ref_integrate_twist.argtypes = [_dp, _dp]
+        R.ref_transform_twist.argtypes = [C.c_double, C.c_double, C.c_double, _dp, _dp]
+        R.ref_dd_convert_twist.argtypes = [_dp, _dp, _dp]
+        R.ref_dd_get_twist.argtypes = [_dp, C.c_double, C.c_double, _dp]
+        R.ref_dd_step.argtypes = [_dp, C.c_double, C.c_double]
+        _ref = R
+    return _ref
