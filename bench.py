@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- EKF-SLAM updates/s on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one tick of the slam node's loop (nuslam/src/slam.cpp:250-319): 1 predict + m sequential
+corrections on one batch of synthetic odometry + range-bearing input that is already resident in HBM.
+
+Workloads
+  ekf1000   (default; BASELINE configs[1]) one EKF per GPU, N = 1000 landmarks, fp64 covariance, m = 16,
+            known association; the map is initialised (one update per landmark) before the timed region.
+            With --gpus N every rank runs its own independent replica (Monte-Carlo trials): weak scaling.
+  batch     (BASELINE configs[3]) --filters independent EKFs of N = 200 landmarks per GPU, one launch per
+            kernel for the whole batch.
+  da1000    (BASELINE configs[4]) as ekf1000 with unknown data association (associateLandmark per marker).
+`value` = corrections (EKF updates) per second over all ranks = ranks * filters * m * steps / seconds.
+
+Extra objects: "roofline" for the dominant kernel (k_update_sweep; algorithmic bytes 2*L^2*w per launch per
+filter, duration from per-dispatch HIP events on the handle's stream) and "cpu_baseline" (the oracle's dense
+mode = the reference's algebra, timed on this host's cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="ekf1000", choices=["ekf1000", "batch", "da1000"])
+    ap.add_argument("--landmarks", type=int, default=None)
+    ap.add_argument("--filters", type=int, default=None, help="filters per GPU (batch workload; default 1024/gpus)")
+    ap.add_argument("--m", type=int, default=16, help="corrections per tick")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not attach HIP events to dispatches in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, m, tr, budget_s, warm_state):
+    """The reference CPU path as restated by oracle/ (dense algebra: 4L^3 per predict, 2L^3 per update), all
+    host cores, on the first ticks of the same trace, from the same post-initialisation snapshot."""
+    import _oracle as O
+    from nuslam_hip import synth
+    cores = O.usable_cpus()
+    O.set_threads(cores)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT, O.ORC_DENSE)
+    o.restore(*warm_state)
+    done = 0
+    t0 = time.perf_counter()
+    while done < tr.ticks and (done == 0 or time.perf_counter() - t0 < budget_s):
+        o.tick(tw=tr.tw[done], mx=tr.mx[done], my=tr.my[done], known_ids=tr.ids[done])
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done * m / dt, "unit": "updates/s", "cores": O.lib().orc_get_threads(), "kind": "port",
+            "sample": "%d tick(s) (1 predict + %d updates each) of the same N=%d trace from the same "
+                      "post-initialisation snapshot, oracle dense mode (reference algebra: two L^3 GEMMs per predict, "
+                      "one per update), %.1f s" % (done, m, n, dt),
+            "ms_per_step": 1e3 * dt / done}, o
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = local_rank if world > 1 else 0
+
+    import nuslam_hip as nh
+    from nuslam_hip import synth
+
+    dtype = nh.F64 if args.dtype == "f64" else nh.F32
+    w = 8 if dtype == nh.F64 else 4
+    if args.workload == "batch":
+        n = args.landmarks or 200
+        B = args.filters or max(1, 1024 // world)
+    else:
+        n = args.landmarks or 1000
+        B = 1
+    m = min(args.m, n)
+    L = 3 + 2 * n
+    K, W = args.steps, args.warmup
+    known = args.workload != "da1000"
+
+    # ---- synthetic input (seeded; Monte-Carlo replica r uses seed 12345 + r), made resident in HBM
+    seed = 12345 + rank
+    tr = synth.make_trace(n, W + K, m, seed=seed)
+    bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed)
+    Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+
+    if B == 1:
+        ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
+        bt = ekf.as_batch()
+        ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
+        ekf.sync()
+        warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and args.cpu_seconds > 0) else None
+    else:
+        bt = nh.Batch(B, n, Q, R, dtype=dtype, device=dev)
+        # initialise every filter's map with one resident warm-up tick of n observations
+        bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+        bt.run(0, 1)
+        bt.sync()
+        warm_state = None
+    ids = tr.ids if known else None
+    bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        bt.sync()
+
+    bt.run(0, W)                       # W untimed warm-up steps
+    barrier()
+    use_events = not args.no_kernel_events
+    bt.profile(use_events)
+    t0 = time.perf_counter()
+    bt.run(W, W + K)                   # EXACTLY K timed steps
+    bt.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    sweep_ms, sweep_n = bt.profile_read(nh.K_UPDATE_SWEEP) if use_events else (0.0, 0)
+    prep_ms, prep_n = bt.profile_read(nh.K_UPDATE_PREPARE) if use_events else (0.0, 0)
+    pred_ms, pred_n = bt.profile_read(nh.K_PREDICT) if use_events else (0.0, 0)
+    asso_ms, asso_n = bt.profile_read(nh.K_ASSOCIATE) if use_events else (0.0, 0)
+    bt.profile(False)
+    bad, st = bt.status()
+    if st != 0:
+        raise RuntimeError("device status %d on filter %d" % (st, bad))
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # the batch reduction over xGMI (RCCL): Monte-Carlo statistics of all replicas, gathered and summed in rank order
+        stats = torch.from_numpy(bt.stats()).cuda()
+        gathered = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        total = torch.stack(gathered).sum(0)
+        n_filters_total = int(total[-1].item())
+    else:
+        n_filters_total = B
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    updates = float(world) * B * m * K
+    out = {
+        "metric": "EKF updates/sec (predict+correct, N landmarks)",
+        "value": updates / dt,
+        "unit": "updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": {"ekf1000": "single EKF per GPU, known association (BASELINE configs[1])",
+                                "batch": "batch of independent EKFs per GPU (BASELINE configs[3])",
+                                "da1000": "single EKF per GPU, unknown data association (BASELINE configs[4])"}[args.workload],
+                   "landmarks": n, "state_len": L, "filters_per_gpu": B, "filters_total": n_filters_total,
+                   "updates_per_step": m, "parallelism": "replicas x%d" % world if B == 1 else "filters sharded x%d" % world,
+                   "kernel_events_in_timed_region": use_events},
+        "ticks_per_s": float(world) * B * K / dt,
+    }
+    if use_events and sweep_n:
+        per_launch_bytes = 2.0 * L * L * w * B           # read + write every P entry once, per filter
+        avg_s = 1e-3 * sweep_ms / sweep_n
+        ach = per_launch_bytes / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_update_sweep", "achieved": ach, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_launch_us": 1e6 * avg_s, "launches": sweep_n,
+                           "algorithmic_bytes_per_launch": per_launch_bytes}
+        out["kernel_us"] = {"update_sweep": 1e3 * sweep_ms / sweep_n,
+                            "update_prepare": 1e3 * prep_ms / max(prep_n, 1),
+                            "predict": 1e3 * pred_ms / max(pred_n, 1),
+                            "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
+    if warm_state is not None and args.cpu_seconds > 0 and args.workload == "ekf1000":
+        cb, _ = cpu_baseline(n, m, synth.make_trace(n, W + K, m, seed=12345), args.cpu_seconds, warm_state)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/*
+ * nuslam_hip.h -- C ABI of the MI355X-native EKF-SLAM predict/update engine.
+ *
+ * This is the drop-in boundary for ONE path of sziselman/Shermbot-Navigation: the nuslam package's
+ * slam_library::ExtendedKalman (nuslam/include/nuslam/slam_library.hpp:23-113, implementation
+ * nuslam/src/slam_library.cpp) as driven by the slam node's loop (nuslam/src/slam.cpp:246-319).
+ * Every entry point names the reference interface it replaces.  Plain pointers and sizes only; the
+ * library owns all device memory.  The shared object is shermbot-navigation_amd/libnuslam_hip.so.
+ *
+ * Conventions
+ *   - state order (theta, x, y, m1x, m1y, ...), length len = 3 + 2n; landmark ids are 1-based
+ *     (slam_library.cpp:152).
+ *   - matrices cross this boundary COLUMN-MAJOR, like arma::mat: X(i,j) = X[i + j*ld].
+ *   - every function returns a status (0 = NUSLAM_OK).  Mutating calls are enqueue-and-return on the
+ *     handle's own HIP stream; getters, nuslam_ekf_associate() and nuslam_ekf_sync() wait for it.
+ *     Failures that the reference would raise as an Armadillo exception inside a call (a full map in
+ *     associateLandmark -> std::logic_error, a singular innovation covariance -> std::runtime_error) are
+ *     detected on the device; they make the offending step a no-op, are latched, and are returned by the
+ *     next synchronising call (and by nuslam_ekf_status()).
+ *   - a handle is not thread-safe; distinct handles may be driven from distinct threads.
+ *   - there is no CPU fallback: without a HIP device every create call fails with NUSLAM_E_NODEV.
+ */
+#ifndef NUSLAM_HIP_H
+#define NUSLAM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NUSLAM_HIP_ABI_VERSION 1
+
+typedef enum {
+    NUSLAM_OK = 0,
+    NUSLAM_E_ARG = 1,       /* null pointer / bad size / bad dtype */
+    NUSLAM_E_BOUNDS = 2,    /* landmark id outside 1..n, or associateLandmark on a full map
+                               (Armadillo: std::logic_error, slam_library.cpp:206-207) */
+    NUSLAM_E_SINGULAR = 3,  /* innovation covariance not invertible (Armadillo inv(): std::runtime_error, :270) */
+    NUSLAM_E_HIP = 4,       /* a HIP runtime call failed; nuslam_last_hip_error() has the text */
+    NUSLAM_E_NODEV = 5,     /* no HIP device available */
+    NUSLAM_E_NOMEM = 6
+} nuslam_status;
+
+typedef enum { NUSLAM_F64 = 0, NUSLAM_F32 = 1 } nuslam_dtype; /* storage type of the covariance in HBM */
+
+typedef struct nuslam_ekf nuslam_ekf_t;     /* one filter            == slam_library::ExtendedKalman */
+typedef struct nuslam_batch nuslam_batch_t; /* B independent filters (Monte-Carlo trials), same n     */
+
+const char* nuslam_strerror(int status);
+const char* nuslam_last_hip_error(void);
+int nuslam_abi_version(void);
+int nuslam_device_count(int* count);
+
+/* ------------------------------------------------------------------ host-side helpers (pure functions) */
+/* slam_library::cartesian2polar, slam_library.cpp:16-22 */
+int nuslam_cartesian2polar(double x, double y, double out_range_bearing[2]);
+/* ExtendedKalman::computeTheoreticalMeasurement(j, state_vec), slam_library.cpp:150-160 */
+int nuslam_measurement(const double* state, int len, int j, double out_range_bearing[2]);
+/* ExtendedKalman::linearizedMeasurementModel(j, state_vec), slam_library.cpp:162-186; H is 2 x len, ld 2 */
+int nuslam_jacobian(const double* state, int len, int j, double* H);
+
+/* ------------------------------------------------------------------ one filter */
+/* ExtendedKalman(colvec robotState, colvec mapState, mat Q, mat R), slam_library.cpp:39-63 (+ initCov :24-33).
+ * map has 2*n_landmarks entries.  dtype selects how the covariance is stored in HBM; state and all
+ * O(len) arithmetic stay fp64. */
+int nuslam_ekf_create(const double robot[3], const double* map, int n_landmarks, const double Q[9],
+                      const double R[4], int dtype, int device, nuslam_ekf_t** out);
+int nuslam_ekf_destroy(nuslam_ekf_t* h);
+/* copy construction / copy assignment of the value type (slam.cpp:157) */
+int nuslam_ekf_clone(const nuslam_ekf_t* h, nuslam_ekf_t** out);
+
+/* ExtendedKalman::predict(const Twist2D&), slam_library.cpp:65-148.  dy is accepted and ignored, as there. */
+int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy);
+/* The covariance propagation of slam_library.cpp:104 for a caller-supplied dense Jacobian:
+ * P <- F P F^T + Qbar, two len^3 products on the matrix cores (MFMA).  F is host memory, len x len,
+ * column-major, leading dimension ldf.  The state is not touched. */
+int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf);
+/* ExtendedKalman::update(const Twist2D&, colvec z, int id), slam_library.cpp:263-282 (the twist is unused there). */
+int nuslam_ekf_update(nuslam_ekf_t* h, double range, double bearing, int id);
+/* ExtendedKalman::associateLandmark(colvec z), slam_library.cpp:188-253.  Synchronises. */
+int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_out);
+/* ExtendedKalman::initializeLandmark(colvec z, int id), slam_library.cpp:255-261 */
+int nuslam_ekf_init_landmark(nuslam_ekf_t* h, double range, double bearing, int id);
+
+/* One iteration of the slam node's loop body, slam.cpp:250-251 + 269-319, entirely on the device:
+ * predict(twist), then for each of the m markers (x, y in the robot frame): cartesian2polar ->
+ * associateLandmark (or the caller's known id) -> initializeLandmark if id > seen-at-tick-start /
+ * skip if id < 0 / stop if id > total_landmarks -> update.  known_ids == NULL selects data association.
+ * ids_out (m ints) may be NULL; when given the call synchronises and reports the id each marker resolved to. */
+int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, const double* mx,
+                    const double* my, const int* known_ids, int total_landmarks, int* ids_out);
+
+/* getStateVector / getCovariance / getSeenLandmarks, slam_library.cpp:284-297.  Synchronise. */
+int nuslam_ekf_len(const nuslam_ekf_t* h, int* len);
+int nuslam_ekf_get_state(nuslam_ekf_t* h, double* out, int len);
+int nuslam_ekf_get_cov(nuslam_ekf_t* h, double* out, int ld);
+int nuslam_ekf_get_seen(nuslam_ekf_t* h, int* seen);
+/* overwrite (state, covariance, seen): checkpoint restore / warm-start fixtures */
+int nuslam_ekf_restore(nuslam_ekf_t* h, const double* state, const double* cov, int ld, int seen);
+int nuslam_ekf_sync(nuslam_ekf_t* h);
+/* latched device-side status (see Conventions); clear != 0 resets it */
+int nuslam_ekf_status(nuslam_ekf_t* h, int clear, int* status_out);
+
+/* ------------------------------------------------------------------ B independent filters */
+/* All filters share n, Q, R and dtype; robot is 3*B, map is 2*n*B (filter-major); either may be NULL (zeros). */
+int nuslam_batch_create(int n_filters, const double* robot, const double* map, int n_landmarks,
+                        const double Q[9], const double R[4], int dtype, int device, nuslam_batch_t** out);
+int nuslam_batch_destroy(nuslam_batch_t* h);
+int nuslam_batch_size(const nuslam_batch_t* h, int* n_filters, int* len);
+/* Make a trace resident in HBM: for filter b, tick t: twist tw[(b*ticks + t)*2 + {0,1}] = (dth, dx) and m
+ * markers mx/my[(b*ticks + t)*m + i] with ids ids[(b*ticks + t)*m + i] (ids == NULL: data association).
+ * bcast != 0: the arrays describe ONE filter and every filter replays them. */
+int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* tw, const double* mx,
+                            const double* my, const int* ids, int bcast);
+/* Run ticks [t_begin, t_end) of the resident trace on every filter (the loop body of slam.cpp:250-319). */
+int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landmarks);
+/* one filter's results (synchronise) */
+int nuslam_batch_get_state(nuslam_batch_t* h, int b, double* out, int len);
+int nuslam_batch_get_cov(nuslam_batch_t* h, int b, double* out, int ld);
+int nuslam_batch_get_seen(nuslam_batch_t* h, int b, int* seen);
+int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const double* cov, int ld, int seen);
+int nuslam_batch_sync(nuslam_batch_t* h);
+int nuslam_batch_status(nuslam_batch_t* h, int clear, int* first_bad_filter, int* status_out);
+/* Batch statistics for the Monte-Carlo reduction: out = { sum_b state (len), sum_b state^2 (len),
+ * sum_b trace(P), count } -- 2*len + 2 doubles, accumulated in filter order (deterministic). */
+int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len);
+/* a one-filter view for the single-filter API above is the batch of size 1: */
+int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do not destroy */
+
+/* ------------------------------------------------------------------ measurement hooks */
+typedef enum {
+    NUSLAM_K_PREDICT = 0,
+    NUSLAM_K_ASSOCIATE = 1,
+    NUSLAM_K_UPDATE_PREPARE = 2,
+    NUSLAM_K_UPDATE_SWEEP = 3,
+    NUSLAM_K_DENSE_GEMM = 4,
+    NUSLAM_K_COUNT = 5
+} nuslam_kernel_id;
+/* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
+ * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */
+int nuslam_batch_profile(nuslam_batch_t* h, int enable);
+/* Synchronises; returns the summed duration and launch count since the last read, then resets. */
+int nuslam_batch_profile_read(nuslam_batch_t* h, int kernel, double* total_ms, long long* launches);
+/* HIP-event stopwatch on the handle's stream (for whole-region timing from a host language) */
+int nuslam_batch_timer_start(nuslam_batch_t* h);
+int nuslam_batch_timer_stop(nuslam_batch_t* h, double* elapsed_ms); /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

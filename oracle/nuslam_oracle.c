@@ -30,13 +30,13 @@ struct orc_ekf {
     double R[4];   /* 2x2 col-major */
 };
 
-static int g_threads = 0; /* 0 = OpenMP default */
+static int g_threads = 1; /* scalar by default; the cpu_baseline leg and large-N checks raise it explicitly */
 
-void orc_set_threads(int nthreads) { g_threads = nthreads > 0 ? nthreads : 0; }
+void orc_set_threads(int nthreads) { g_threads = nthreads > 0 ? nthreads : 1; }
 int orc_get_threads(void)
 {
 #ifdef _OPENMP
-    return g_threads > 0 ? g_threads : omp_get_max_threads();
+    return g_threads;
 #else
     return 1;
 #endif

@@ -1,0 +1,176 @@
+// dense_predict.hip -- P <- F P F^T + Qbar as two LDS-tiled MFMA GEMMs for gfx950 (wave64).
+//
+// Reference: the dense covariance propagation `A * covariance * A.t() + Q_bar` of nuslam/src/slam_library.cpp:104
+// (4 len^3 flop).  For the reference's own motion model A = I + B has two non-zeros and k_predict does the same
+// job in O(len); this path serves a caller-supplied dense Jacobian (nuslam_ekf_predict_dense) and is the one
+// MFMA-bound kernel of the engine.
+//
+// Matrix cores used: v_mfma_f32_32x32x2_f32 (exact f32 fma chain) / v_mfma_f64_16x16x4_f64.
+// Everything is column-major.  Output tiles are produced with the MFMA "N" index (the lane) running along the
+// rows of C, so stores are 128-byte coalesced along the contiguous dimension: the MFMA B operand is our A tile,
+// the MFMA A operand is our B tile.
+#include "dense_predict.h"
+
+#include <hip/hip_ext.h>
+
+namespace {
+
+template <typename T> struct Mfma;
+
+template <> struct Mfma<float> {
+    static constexpr int TM = 32;   // tile edge
+    static constexpr int TK = 2;    // k per instruction
+    static constexpr int NACC = 16; // accumulator registers per lane
+    typedef float acc_t __attribute__((ext_vector_type(16)));
+    static __device__ inline acc_t run(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+    static __device__ inline int idx(int lane) { return lane & 31; }
+    static __device__ inline int kk(int lane) { return lane >> 5; }
+    static __device__ inline int row(int lane, int r) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+};
+
+template <> struct Mfma<double> {
+    static constexpr int TM = 16;
+    static constexpr int TK = 4;
+    static constexpr int NACC = 4;
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ inline acc_t run(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ inline int idx(int lane) { return lane & 15; }
+    static __device__ inline int kk(int lane) { return lane >> 4; }
+    static __device__ inline int row(int lane, int r) { return (lane >> 4) + 4 * r; }   // f64 C/D map differs from f32
+};
+
+template <typename T> struct alignas(16) V16 { T v[16 / sizeof(T)]; };
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+// C(i,j) = sum_k A(i,k) * Bop(k,j) [+ Q(i,j) on the 3x3 corner]
+//   A   : (i,k) at A[i + k*ld]                         (contiguous along i)
+//   Bop : B_KMAJOR ? B[k + j*ld] : B[j + k*ld]         (first GEMM: B = P, k-major; second: B = F used as F^T)
+// 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 sub-tile.
+template <typename T, bool B_KMAJOR, bool ADD_Q>
+__global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict__ A, const T* __restrict__ B,
+                                              T* __restrict__ C, double q00, double q10, double q20, double q01,
+                                              double q11, double q21, double q02, double q12, double q22)
+{
+    typedef Mfma<T> M;
+    typedef typename M::acc_t acc_t;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NT = 64 / M::TM;            // MFMA tiles per wave edge
+    constexpr int PB = B_KMAJOR ? 1 : 0;      // odd row stride -> conflict-free transposing stores
+    __shared__ T As[BK][BM];
+    __shared__ T Bs[BK][BN + PB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int it = (wave & 1) * 64, jt = (wave >> 1) * 64;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    const int idx = M::idx(lane), kk = M::kk(lane);
+
+    acc_t acc[NT][NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = 0;
+
+    for (int k0 = 0; k0 < L; k0 += BK) {
+        // ---- stage A tile: BK rows of k, BM contiguous i
+        constexpr int AV = BM / VEC;                 // vectors per k-row
+#pragma unroll
+        for (int s = 0; s < (BK * AV) / 256; ++s) {
+            const int v = tid + s * 256;
+            const int k = v / AV, iv = (v % AV) * VEC;
+            V16<T> x;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x.v[e] = 0;
+            if (k0 + k < L && i0 + iv < ld) x = *reinterpret_cast<const V16<T>*>(A + (size_t)(k0 + k) * ld + i0 + iv);
+            *reinterpret_cast<V16<T>*>(&As[k][iv]) = x;
+        }
+        // ---- stage B tile into Bs[k][j]
+        if (B_KMAJOR) {
+            constexpr int KV = BK / VEC;             // vectors per column
+#pragma unroll
+            for (int s = 0; s < (BN * KV) / 256; ++s) {
+                const int v = tid + s * 256;
+                const int kq = (v % KV) * VEC, j = v / KV;
+                V16<T> x;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x.v[e] = 0;
+                if (j0 + j < L && k0 + kq < ld) x = *reinterpret_cast<const V16<T>*>(B + (size_t)(j0 + j) * ld + k0 + kq);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) Bs[kq + e][j] = x.v[e];
+            }
+        } else {
+            constexpr int BV = BN / VEC;
+#pragma unroll
+            for (int s = 0; s < (BK * BV) / 256; ++s) {
+                const int v = tid + s * 256;
+                const int k = v / BV, jv = (v % BV) * VEC;
+                V16<T> x;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) x.v[e] = 0;
+                if (k0 + k < L && j0 + jv < ld) x = *reinterpret_cast<const V16<T>*>(B + (size_t)(k0 + k) * ld + j0 + jv);
+                *reinterpret_cast<V16<T>*>(&Bs[k][jv]) = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += M::TK) {
+            T af[NT], bf[NT];
+#pragma unroll
+            for (int a = 0; a < NT; ++a) af[a] = Bs[ks + kk][jt + a * M::TM + idx];   // MFMA A operand <- our B tile
+#pragma unroll
+            for (int b = 0; b < NT; ++b) bf[b] = As[ks + kk][it + b * M::TM + idx];   // MFMA B operand <- our A tile
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) acc[a][b] = M::run(af[a], bf[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane <-> row i (contiguous), register <-> column j
+    const double q[9] = { q00, q10, q20, q01, q11, q21, q02, q12, q22 };
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            const int i = i0 + it + b * M::TM + idx;
+#pragma unroll
+            for (int r = 0; r < M::NACC; ++r) {
+                const int j = j0 + jt + a * M::TM + M::row(lane, r);
+                if (i < L && j < L) {
+                    T val = acc[a][b][r];
+                    if (ADD_Q && i < 3 && j < 3) val = (T)((double)val + q[i + 3 * j]);
+                    C[(size_t)j * ld + i] = val;
+                }
+            }
+        }
+}
+
+template <typename T>
+int run_t(int L, int ld, const T* F, T* P, T* Tw, const double Q[9], hipStream_t stream, hipEvent_t ev[4])
+{
+    dim3 grid((L + BM - 1) / BM, (L + BN - 1) / BN), block(256);
+    // T = F * P            (slam_library.cpp:104, left product first)
+    hipExtLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, stream, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0,
+                          L, ld, F, (const T*)P, Tw, 0., 0., 0., 0., 0., 0., 0., 0., 0.);
+    if (hipGetLastError() != hipSuccess) return 1;
+    // P = T * F^T + Qbar
+    hipExtLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, stream, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, 0,
+                          L, ld, (const T*)Tw, F, P, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8]);
+    if (hipGetLastError() != hipSuccess) return 1;
+    return 0;
+}
+
+} // namespace
+
+int dense_predict_launch(int dtype, int L, int ld, const void* F, void* P, void* T, const double Q[9],
+                         hipStream_t stream, hipEvent_t ev[4])
+{
+    hipEvent_t* e = (ev && ev[0]) ? ev : nullptr;
+    if (dtype == 1) return run_t<float>(L, ld, (const float*)F, (float*)P, (float*)T, Q, stream, e);
+    return run_t<double>(L, ld, (const double*)F, (double*)P, (double*)T, Q, stream, e);
+}

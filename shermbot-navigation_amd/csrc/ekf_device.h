@@ -1,0 +1,161 @@
+// ekf_device.h -- device-side math of the EKF-SLAM hot path (gfx950).
+//
+// Every function states the reference lines it computes (paths relative to the reference checkout).
+// This translation unit is compiled with -ffp-contract=off: each multiply and add is rounded on its own,
+// in the order written, which is also how the CPU oracle is built -- the two sides then differ only in
+// libm (sin/cos/atan2), never in the covariance algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+namespace nuslam {
+
+// ctrl words per filter (double-buffered, see View)
+enum { C_SEEN = 0, C_SEEN_CACHED = 1, C_BRK = 2, C_STATUS = 3, C_WORDS = 4 };
+// decision record written by update_prepare, read by update_sweep
+enum { D_SKIP = 0, D_COL = 1, D_WORDS = 4 };
+// how update_prepare resolves the landmark id and whether the slam.cpp decision chain applies
+enum { MODE_FORCE = 0, MODE_KNOWN = 1, MODE_DA = 2 };
+
+struct View {
+    int n, L, ld, B;
+    const double* s_in;   // [B][ld]   state before this kernel
+    double* s_out;        // [B][ld]   state after  (host flips the pair after every state-writing kernel)
+    const int* c_in;      // [B][C_WORDS]
+    int* c_out;
+    long long p_stride;   // elements between consecutive filters' covariance (ld * L)
+    int* dec;             // [B][D_WORDS]
+    int* cur_id;          // [B] id resolved by associate
+    int* id_log;          // [B][log_stride] resolved id per observation of the current tick (may be null)
+    int log_stride;
+    double Q[9];          // 3x3 column-major process noise   (slam_library.hpp:27)
+    double R[4];          // 2x2 column-major sensor noise    (slam_library.hpp:28)
+};
+
+// One observation per filter: either inline (single-filter API) or from a trace resident in HBM.
+struct ObsArg {
+    const double* a;     // marker x (cartesian != 0) or range; null -> inline a0
+    const double* b;     // marker y or bearing
+    const int* ids;      // known 1-based ids; null -> inline id0 (MODE_FORCE / MODE_KNOWN) or cur_id (MODE_DA)
+    long long stride;    // per-filter stride in elements (0 = every filter reads the same trace)
+    long long off;       // element offset of this observation
+    double a0, b0;
+    int id0;
+    int cartesian;
+    int log_slot;        // index into id_log, or -1
+};
+
+struct TwistArg {
+    const double* tw;    // (dth, dx) pairs; null -> inline
+    long long stride, off;
+    double dth0, dx0;
+};
+
+__device__ inline double normalize_angle(double rad)       // rigid2d/src/rigid2d.cpp:9-13
+{
+    return atan2(sin(rad), cos(rad));
+}
+
+__device__ inline void cartesian2polar(double x, double y, double& r, double& b) // slam_library.cpp:16-22
+{
+    r = sqrt((x * x) + (y * y));
+    b = normalize_angle(atan2(y, x));
+}
+
+__device__ inline void fetch_obs(const ObsArg& o, int bidx, double& r, double& phi)
+{
+    double a = o.a ? o.a[bidx * o.stride + o.off] : o.a0;
+    double b = o.b ? o.b[bidx * o.stride + o.off] : o.b0;
+    if (o.cartesian) cartesian2polar(a, b, r, phi);        // slam.cpp:286
+    else { r = a; phi = b; }
+}
+
+// computeTheoreticalMeasurement with the five state entries it reads, slam_library.cpp:150-160
+__device__ inline void measurement(double th, double x, double y, double lx, double ly, double& zr, double& zb)
+{
+    const double mx = lx - x;
+    const double my = ly - y;
+    cartesian2polar(mx, my, zr, zb);
+    zb = normalize_angle(zb - th);
+}
+
+// linearizedMeasurementModel, slam_library.cpp:162-186: the nine non-zeros, Hc[r + 2q] = H(r, set[q]),
+// set = {0, 1, 2, c, c+1}
+__device__ inline void jacobian_compact(double x, double y, double lx, double ly, double Hc[10])
+{
+    const double dx = lx - x;
+    const double dy = ly - y;
+    const double d = (dx * dx) + (dy * dy);
+    const double sd = sqrt(d);
+    Hc[0] = 0.0;       Hc[1] = -1.0;
+    Hc[2] = -dx / sd;  Hc[3] = dy / d;
+    Hc[4] = -dy / sd;  Hc[5] = -dx / d;
+    Hc[6] = dx / sd;   Hc[7] = -dy / d;
+    Hc[8] = dy / sd;   Hc[9] = dx / d;
+}
+
+// inv() / .i() of a 2x2 as Armadillo 9.800 evaluates it (auxlib::inv_noalias_tinymat; general LU when
+// |det| < epsilon).  Column-major in and out.  Returns 0, or 1 when exactly singular.
+__device__ inline int inv2(const double X[4], double out[4])
+{
+    const double a = X[0], c = X[1], b = X[2], d = X[3];
+    const double det = (a * d) - (b * c);
+    if (fabs(det) >= DBL_EPSILON) {
+        out[0] = d / det;
+        out[2] = -b / det;
+        out[1] = -c / det;
+        out[3] = a / det;
+        return 0;
+    }
+    double r00 = a, r01 = b, r10 = c, r11 = d;
+    bool swp = false;
+    if (fabs(r10) > fabs(r00)) { double t0 = r00, t1 = r01; r00 = r10; r01 = r11; r10 = t0; r11 = t1; swp = true; }
+    if (r00 == 0.0) return 1;
+    const double l = r10 / r00;
+    const double u11 = r11 - l * r01;
+    if (u11 == 0.0 || u11 != u11) return 1;
+    double inv[4];
+    for (int col = 0; col < 2; ++col) {
+        const double e0 = col == 0 ? 1.0 : 0.0, e1 = col == 1 ? 1.0 : 0.0;
+        const double y1 = e1 - l * e0;
+        const double x1 = y1 / u11;
+        const double x0 = (e0 - r01 * x1) / r00;
+        inv[0 + 2 * col] = x0;
+        inv[1 + 2 * col] = x1;
+    }
+    if (swp) { out[0] = inv[2]; out[1] = inv[3]; out[2] = inv[0]; out[3] = inv[1]; }
+    else { out[0] = inv[0]; out[1] = inv[1]; out[2] = inv[2]; out[3] = inv[3]; }
+    return 0;
+}
+
+// psi = H P H^T + R from the 5x5 block of P at rows/cols set (slam_library.cpp:215,270), ascending-k sums.
+template <typename T>
+__device__ inline void innovation_cov(const T* __restrict__ Pb, int ld, const int set[5], const double Hc[10],
+                                      const double R[4], double S[4])
+{
+    double HPs[2][5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double p[5];
+#pragma unroll
+        for (int q2 = 0; q2 < 5; ++q2) p[q2] = (double)Pb[(size_t)set[q] * ld + set[q2]];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q2 = 0; q2 < 5; ++q2) acc = acc + Hc[r + 2 * q2] * p[q2];
+            HPs[r][q] = acc;
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) acc = acc + HPs[r][q] * Hc[s2 + 2 * q];
+            S[r + 2 * s2] = acc + R[r + 2 * s2];
+        }
+}
+
+} // namespace nuslam

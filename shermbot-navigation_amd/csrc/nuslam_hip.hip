@@ -1,0 +1,815 @@
+// nuslam_hip.hip -- host side of the C ABI declared in include/nuslam_hip.h: owns the device memory of a batch
+// of filters, flips the state/control double buffers, and launches the kernels of ekf_kernels.h on the
+// handle's own stream.  A single filter (nuslam_ekf_t) is a batch of one.
+//
+// There is no CPU fallback anywhere in this file: every entry point either runs HIP kernels or fails.
+#include "../../include/nuslam_hip.h"
+#include "ekf_kernels.h"
+#include "dense_predict.h"
+
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace nuslam;
+
+namespace {
+
+thread_local std::string g_hip_err;
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e__);                            \
+            return NUSLAM_E_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+constexpr int kSweepCW = 16;  // columns per wave in the sweep
+
+inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
+
+} // namespace
+
+struct nuslam_batch {
+    int device = 0;
+    int n = 0, L = 0, ld = 0, B = 0, dtype = 0;
+    hipStream_t stream = nullptr;
+    double* state[2] = { nullptr, nullptr };
+    int* ctrl[2] = { nullptr, nullptr };
+    int sidx = 0, cidx = 0;
+    void* P = nullptr;
+    long long p_stride = 0;
+    double* Mc = nullptr;
+    double* Rw = nullptr;
+    int* dec = nullptr;
+    int* cur_id = nullptr;
+    double* tr = nullptr;      // per-filter trace scratch
+    double* stats = nullptr;   // 2L + 2
+    double Q[9], R[4];
+    // resident trace
+    double* tr_tw = nullptr; double* tr_mx = nullptr; double* tr_my = nullptr; int* tr_ids = nullptr;
+    int tr_ticks = 0, tr_m = 0, tr_bcast = 0;
+    // staging for nuslam_ekf_tick (one filter, m observations)
+    double* st_mx = nullptr; double* st_my = nullptr; int* st_ids = nullptr; int* id_log = nullptr;
+    int st_cap = 0, log_stride = 0;
+    // dense predict workspaces (element type = dtype)
+    void* wF = nullptr; void* wT = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[NUSLAM_K_COUNT];
+    std::vector<hipEvent_t> pool;
+    double prof_ms[NUSLAM_K_COUNT] = { 0 };
+    long long prof_n[NUSLAM_K_COUNT] = { 0 };
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+
+    size_t esize() const { return dtype == NUSLAM_F32 ? 4 : 8; }
+
+    View view() const
+    {
+        View v;
+        v.n = n; v.L = L; v.ld = ld; v.B = B;
+        v.s_in = state[sidx]; v.s_out = state[sidx ^ 1];
+        v.c_in = ctrl[cidx]; v.c_out = ctrl[cidx ^ 1];
+        v.p_stride = p_stride;
+        v.dec = dec; v.cur_id = cur_id; v.id_log = id_log; v.log_stride = log_stride;
+        memcpy(v.Q, Q, sizeof(Q));
+        memcpy(v.R, R, sizeof(R));
+        return v;
+    }
+};
+
+struct nuslam_ekf {
+    nuslam_batch* core;
+};
+
+namespace {
+
+hipEvent_t get_event(nuslam_batch* h)
+{
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Launch on the handle's stream; with profiling on, the dispatch carries its own start/stop events.
+template <typename... KArgs, typename... Args>
+int launch(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, Args... args)
+{
+    if (h->prof && kid >= 0) {
+        hipEvent_t e0 = get_event(h), e1 = get_event(h);
+        if (!e0 || !e1) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; }
+        hipExtLaunchKernelGGL(kern, grid, block, 0, h->stream, e0, e1, 0, args...);
+        h->pending[kid].emplace_back(e0, e1);
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+    }
+    HIPCHK(hipGetLastError());
+    return NUSLAM_OK;
+}
+
+int drain_profile(nuslam_batch* h)
+{
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < NUSLAM_K_COUNT; ++k) {
+        for (auto& pr : h->pending[k]) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            h->prof_ms[k] += ms;
+            h->prof_n[k] += 1;
+            h->pool.push_back(pr.first);
+            h->pool.push_back(pr.second);
+        }
+        h->pending[k].clear();
+    }
+    return NUSLAM_OK;
+}
+
+#define DISPATCH_T(h, CALL)                                   \
+    do {                                                      \
+        if ((h)->dtype == NUSLAM_F32) { typedef float T; CALL; } \
+        else { typedef double T; CALL; }                      \
+    } while (0)
+
+int do_predict(nuslam_batch* h, const TwistArg& tw)
+{
+    View v = h->view();
+    dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, NUSLAM_K_PREDICT, k_predict<T>, grid, block, v, tw, (T*)h->P));
+    if (rc) return rc;
+    h->sidx ^= 1;
+    h->cidx ^= 1;
+    return NUSLAM_OK;
+}
+
+int do_associate(nuslam_batch* h, const ObsArg& o)
+{
+    View v = h->view();
+    dim3 grid(h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, NUSLAM_K_ASSOCIATE, k_associate<T>, grid, block, v, o, (const T*)h->P));
+    if (rc) return rc;
+    h->cidx ^= 1;
+    return NUSLAM_OK;
+}
+
+int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
+{
+    View v = h->view();
+    dim3 gridp((h->ld + 255) / 256, 1, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, NUSLAM_K_UPDATE_PREPARE, k_update_prepare<T>, gridp, block, v, o, mode, total,
+                              (const T*)h->P, h->Mc, h->Rw));
+    if (rc) return rc;
+    h->sidx ^= 1;
+    h->cidx ^= 1;
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    dim3 grids((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B);
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE_SWEEP, k_update_sweep<T, kSweepCW>, grids, block, v, (T*)h->P,
+                               (const double*)h->Mc, (const double*)h->Rw)));
+    return rc;
+}
+
+// One loop body of slam.cpp:250-319 for every filter of the batch.
+int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total)
+{
+    int rc = do_predict(h, tw);
+    if (rc) return rc;
+    for (int i = 0; i < m; ++i) {
+        ObsArg o = base;
+        o.off = base.off + i;
+        o.log_slot = h->id_log ? i : -1;
+        if (!known) {
+            rc = do_associate(h, o);
+            if (rc) return rc;
+        }
+        rc = do_update(h, o, known ? MODE_KNOWN : MODE_DA, total);
+        if (rc) return rc;
+    }
+    return NUSLAM_OK;
+}
+
+void free_batch(nuslam_batch* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->P, h->Mc, h->Rw, h->dec, h->cur_id, h->tr,
+                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->wF, h->wT };
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int k = 0; k < NUSLAM_K_COUNT; ++k)
+        for (auto& pr : h->pending[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : h->pool) (void)hipEventDestroy(e);
+    if (h->t0) (void)hipEventDestroy(h->t0);
+    if (h->t1) (void)hipEventDestroy(h->t1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return NUSLAM_E_NODEV;
+    }
+    if (device < 0 || device >= count) return NUSLAM_E_ARG;
+    nuslam_batch* h = new (std::nothrow) nuslam_batch();
+    if (!h) return NUSLAM_E_NOMEM;
+    h->device = device; h->B = B; h->n = n; h->L = 3 + 2 * n; h->ld = roundup(h->L, 32); h->dtype = dtype;
+    h->p_stride = (long long)h->ld * h->L;
+    int rc = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        const size_t sb = sizeof(double) * (size_t)B * h->ld;
+        HIPCHK(hipMalloc(&h->state[0], sb));
+        HIPCHK(hipMalloc(&h->state[1], sb));
+        HIPCHK(hipMalloc(&h->ctrl[0], sizeof(int) * B * C_WORDS));
+        HIPCHK(hipMalloc(&h->ctrl[1], sizeof(int) * B * C_WORDS));
+        HIPCHK(hipMalloc(&h->P, h->esize() * (size_t)B * h->p_stride));
+        HIPCHK(hipMalloc(&h->Mc, sb * 5));
+        HIPCHK(hipMalloc(&h->Rw, sb * 5));
+        HIPCHK(hipMalloc(&h->dec, sizeof(int) * B * D_WORDS));
+        HIPCHK(hipMalloc(&h->cur_id, sizeof(int) * B));
+        HIPCHK(hipMalloc(&h->tr, sizeof(double) * B));
+        HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 2)));
+        HIPCHK(hipMemsetAsync(h->dec, 0, sizeof(int) * B * D_WORDS, h->stream));
+        HIPCHK(hipMemsetAsync(h->cur_id, 0, sizeof(int) * B, h->stream));
+        HIPCHK(hipEventCreate(&h->t0));
+        HIPCHK(hipEventCreate(&h->t1));
+        return NUSLAM_OK;
+    }();
+    if (rc) { free_batch(h); return rc; }
+    *out = h;
+    return NUSLAM_OK;
+}
+
+int init_batch(nuslam_batch* h, const double* robot, const double* map, const double Q[9], const double R[4])
+{
+    memcpy(h->Q, Q, sizeof(h->Q));
+    memcpy(h->R, R, sizeof(h->R));
+    double* d_robot = nullptr;
+    double* d_map = nullptr;
+    HIPCHK(hipSetDevice(h->device));
+    if (robot) {
+        HIPCHK(hipMalloc(&d_robot, sizeof(double) * 3 * h->B));
+        HIPCHK(hipMemcpyAsync(d_robot, robot, sizeof(double) * 3 * h->B, hipMemcpyHostToDevice, h->stream));
+    }
+    if (map && h->n > 0) {
+        HIPCHK(hipMalloc(&d_map, sizeof(double) * 2 * h->n * (size_t)h->B));
+        HIPCHK(hipMemcpyAsync(d_map, map, sizeof(double) * 2 * h->n * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(hipMemsetAsync(h->P, 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
+    View v = h->view();
+    dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, -1, k_init<T>, grid, block, v, (const double*)d_robot, (const double*)d_map, (T*)h->P,
+                              h->state[0], h->state[1], h->ctrl[0], h->ctrl[1]));
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (d_robot) (void)hipFree(d_robot);
+    if (d_map) (void)hipFree(d_map);
+    if (rc) return rc;
+    HIPCHK(e);
+    h->sidx = 0; h->cidx = 0;
+    return NUSLAM_OK;
+}
+
+int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
+{
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<int> c((size_t)h->B * C_WORDS);
+    HIPCHK(hipMemcpy(c.data(), h->ctrl[h->cidx], sizeof(int) * c.size(), hipMemcpyDeviceToHost));
+    int st = 0, bad = -1;
+    for (int b = 0; b < h->B; ++b)
+        if (c[(size_t)b * C_WORDS + C_STATUS] != 0) { st = c[(size_t)b * C_WORDS + C_STATUS]; bad = b; break; }
+    if (clear && st) {
+        for (int b = 0; b < h->B; ++b) c[(size_t)b * C_WORDS + C_STATUS] = 0;
+        HIPCHK(hipMemcpy(h->ctrl[h->cidx], c.data(), sizeof(int) * c.size(), hipMemcpyHostToDevice));
+    }
+    if (first_bad) *first_bad = bad;
+    if (status_out) *status_out = st;
+    return NUSLAM_OK;
+}
+
+int get_state(nuslam_batch* h, int b, double* out, int len)
+{
+    if (!h || !out || b < 0 || b >= h->B || len < h->L) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->state[h->sidx] + (size_t)b * h->ld, sizeof(double) * h->L, hipMemcpyDeviceToHost));
+    return NUSLAM_OK;
+}
+
+int get_cov(nuslam_batch* h, int b, double* out, int ld)
+{
+    if (!h || !out || b < 0 || b >= h->B || ld < h->L) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const char* src = (const char*)h->P + h->esize() * (size_t)b * h->p_stride;
+    if (h->dtype == NUSLAM_F64) {
+        HIPCHK(hipMemcpy2D(out, sizeof(double) * ld, src, sizeof(double) * h->ld, sizeof(double) * h->L, h->L,
+                           hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp((size_t)h->L * h->L);
+        HIPCHK(hipMemcpy2D(tmp.data(), sizeof(float) * h->L, src, sizeof(float) * h->ld, sizeof(float) * h->L, h->L,
+                           hipMemcpyDeviceToHost));
+        for (int j = 0; j < h->L; ++j)
+            for (int i = 0; i < h->L; ++i) out[i + (size_t)j * ld] = (double)tmp[i + (size_t)j * h->L];
+    }
+    return NUSLAM_OK;
+}
+
+int get_seen(nuslam_batch* h, int b, int* seen)
+{
+    if (!h || !seen || b < 0 || b >= h->B) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(seen, h->ctrl[h->cidx] + (size_t)b * C_WORDS + C_SEEN, sizeof(int), hipMemcpyDeviceToHost));
+    return NUSLAM_OK;
+}
+
+int restore(nuslam_batch* h, int b, const double* state, const double* cov, int ld, int seen)
+{
+    if (!h || !state || !cov || b < 0 || b >= h->B || ld < h->L || seen < 0 || seen > h->n) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> s(h->ld, 0.0);
+    memcpy(s.data(), state, sizeof(double) * h->L);
+    HIPCHK(hipMemcpy(h->state[h->sidx] + (size_t)b * h->ld, s.data(), sizeof(double) * h->ld, hipMemcpyHostToDevice));
+    char* dst = (char*)h->P + h->esize() * (size_t)b * h->p_stride;
+    if (h->dtype == NUSLAM_F64) {
+        HIPCHK(hipMemcpy2D(dst, sizeof(double) * h->ld, cov, sizeof(double) * ld, sizeof(double) * h->L, h->L,
+                           hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp((size_t)h->L * h->L);
+        for (int j = 0; j < h->L; ++j)
+            for (int i = 0; i < h->L; ++i) tmp[i + (size_t)j * h->L] = (float)cov[i + (size_t)j * ld];
+        HIPCHK(hipMemcpy2D(dst, sizeof(float) * h->ld, tmp.data(), sizeof(float) * h->L, sizeof(float) * h->L, h->L,
+                           hipMemcpyHostToDevice));
+    }
+    int c[C_WORDS] = { seen, seen, 0, 0 };
+    HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
+    return NUSLAM_OK;
+}
+
+// latched device status -> return code of a synchronising call
+int sync_status(nuslam_batch* h)
+{
+    int st = 0;
+    int rc = read_status(h, 0, nullptr, &st);
+    return rc ? rc : st;
+}
+
+int ensure_stage(nuslam_batch* h, int m)
+{
+    if (m <= h->st_cap) return NUSLAM_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    void* olds[] = { h->st_mx, h->st_my, h->st_ids, h->id_log };
+    for (void* p : olds)
+        if (p) (void)hipFree(p);
+    h->st_mx = h->st_my = nullptr; h->st_ids = nullptr; h->id_log = nullptr; h->st_cap = 0;
+    const int cap = roundup(m, 64);
+    HIPCHK(hipMalloc(&h->st_mx, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&h->st_my, sizeof(double) * cap));
+    HIPCHK(hipMalloc(&h->st_ids, sizeof(int) * cap));
+    HIPCHK(hipMalloc(&h->id_log, sizeof(int) * cap * (size_t)h->B));
+    h->st_cap = cap;
+    h->log_stride = cap;
+    return NUSLAM_OK;
+}
+
+} // namespace
+
+// =============================================================================================== C ABI
+extern "C" {
+
+const char* nuslam_strerror(int status)
+{
+    switch (status) {
+    case NUSLAM_OK: return "ok";
+    case NUSLAM_E_ARG: return "invalid argument";
+    case NUSLAM_E_BOUNDS: return "landmark index out of bounds (Armadillo: std::logic_error)";
+    case NUSLAM_E_SINGULAR: return "innovation covariance singular (Armadillo inv(): std::runtime_error)";
+    case NUSLAM_E_HIP: return "HIP runtime error";
+    case NUSLAM_E_NODEV: return "no HIP device";
+    case NUSLAM_E_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char* nuslam_last_hip_error(void) { return g_hip_err.c_str(); }
+int nuslam_abi_version(void) { return NUSLAM_HIP_ABI_VERSION; }
+
+int nuslam_device_count(int* count)
+{
+    if (!count) return NUSLAM_E_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+    *count = c;
+    return NUSLAM_OK;
+}
+
+// ---- host-side pure helpers (public methods of the reference class that take a caller-supplied vector)
+static double h_normalize_angle(double rad) { return std::atan2(std::sin(rad), std::cos(rad)); }
+
+int nuslam_cartesian2polar(double x, double y, double out[2])
+{
+    if (!out) return NUSLAM_E_ARG;
+    out[0] = std::sqrt((x * x) + (y * y));
+    out[1] = h_normalize_angle(std::atan2(y, x));
+    return NUSLAM_OK;
+}
+
+int nuslam_measurement(const double* s, int len, int j, double out[2])
+{
+    if (!s || !out) return NUSLAM_E_ARG;
+    if (j < 1 || 4 + 2 * (j - 1) >= len) return NUSLAM_E_BOUNDS;
+    nuslam_cartesian2polar(s[3 + 2 * (j - 1)] - s[1], s[4 + 2 * (j - 1)] - s[2], out);
+    out[1] = h_normalize_angle(out[1] - s[0]);
+    return NUSLAM_OK;
+}
+
+int nuslam_jacobian(const double* s, int len, int j, double* H)
+{
+    if (!s || !H) return NUSLAM_E_ARG;
+    if (j < 1 || 4 + 2 * (j - 1) >= len) return NUSLAM_E_BOUNDS;
+    for (int i = 0; i < 2 * len; ++i) H[i] = 0.0;
+    const int c = 3 + 2 * (j - 1);
+    const double dx = s[c] - s[1], dy = s[c + 1] - s[2];
+    const double d = (dx * dx) + (dy * dy);
+    H[1 + 2 * 0] = -1;
+    H[0 + 2 * 1] = -dx / std::sqrt(d);  H[1 + 2 * 1] = dy / d;
+    H[0 + 2 * 2] = -dy / std::sqrt(d);  H[1 + 2 * 2] = -dx / d;
+    H[0 + 2 * c] = dx / std::sqrt(d);   H[1 + 2 * c] = -dy / d;
+    H[0 + 2 * (c + 1)] = dy / std::sqrt(d);  H[1 + 2 * (c + 1)] = dx / d;
+    return NUSLAM_OK;
+}
+
+// ---- batch
+int nuslam_batch_create(int n_filters, const double* robot, const double* map, int n_landmarks, const double Q[9],
+                        const double R[4], int dtype, int device, nuslam_batch_t** out)
+{
+    if (!out || !Q || !R || n_filters < 1 || n_landmarks < 0 || (dtype != NUSLAM_F64 && dtype != NUSLAM_F32))
+        return NUSLAM_E_ARG;
+    nuslam_batch* h = nullptr;
+    int rc = alloc_batch(n_filters, n_landmarks, dtype, device, &h);
+    if (rc) return rc;
+    rc = init_batch(h, robot, map, Q, R);
+    if (rc) { free_batch(h); return rc; }
+    *out = h;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_destroy(nuslam_batch_t* h)
+{
+    free_batch(h);
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_size(const nuslam_batch_t* h, int* n_filters, int* len)
+{
+    if (!h) return NUSLAM_E_ARG;
+    if (n_filters) *n_filters = h->B;
+    if (len) *len = h->L;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* tw, const double* mx, const double* my,
+                            const int* ids, int bcast)
+{
+    if (!h || ticks < 1 || m < 0 || !tw || (m > 0 && (!mx || !my))) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    void* olds[] = { h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids };
+    for (void* p : olds)
+        if (p) (void)hipFree(p);
+    h->tr_tw = h->tr_mx = h->tr_my = nullptr; h->tr_ids = nullptr;
+    const size_t nb = bcast ? 1 : (size_t)h->B;
+    const size_t mm = m > 0 ? (size_t)m : 1;
+    HIPCHK(hipMalloc(&h->tr_tw, sizeof(double) * nb * ticks * 2));
+    HIPCHK(hipMemcpy(h->tr_tw, tw, sizeof(double) * nb * ticks * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->tr_mx, sizeof(double) * nb * ticks * mm));
+    HIPCHK(hipMalloc(&h->tr_my, sizeof(double) * nb * ticks * mm));
+    if (m > 0) {
+        HIPCHK(hipMemcpy(h->tr_mx, mx, sizeof(double) * nb * ticks * m, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->tr_my, my, sizeof(double) * nb * ticks * m, hipMemcpyHostToDevice));
+        if (ids) {
+            HIPCHK(hipMalloc(&h->tr_ids, sizeof(int) * nb * ticks * m));
+            HIPCHK(hipMemcpy(h->tr_ids, ids, sizeof(int) * nb * ticks * m, hipMemcpyHostToDevice));
+        }
+    }
+    h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = bcast ? 1 : 0;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landmarks)
+{
+    if (!h || !h->tr_tw || t_begin < 0 || t_end > h->tr_ticks || t_begin > t_end) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int* saved_log = h->id_log;
+    h->id_log = nullptr;  // resident traces do not log resolved ids
+    int rc = NUSLAM_OK;
+    for (int t = t_begin; t < t_end && !rc; ++t) {
+        TwistArg tw;
+        tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
+        tw.dth0 = tw.dx0 = 0.0;
+        ObsArg o;
+        o.a = h->tr_mx; o.b = h->tr_my; o.ids = h->tr_ids;
+        o.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * h->tr_m;
+        o.off = (long long)t * h->tr_m;
+        o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
+        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks);
+    }
+    h->id_log = saved_log;
+    return rc;
+}
+
+int nuslam_batch_get_state(nuslam_batch_t* h, int b, double* out, int len) { return get_state(h, b, out, len); }
+int nuslam_batch_get_cov(nuslam_batch_t* h, int b, double* out, int ld) { return get_cov(h, b, out, ld); }
+int nuslam_batch_get_seen(nuslam_batch_t* h, int b, int* seen) { return get_seen(h, b, seen); }
+int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const double* cov, int ld, int seen)
+{
+    return restore(h, b, state, cov, ld, seen);
+}
+
+int nuslam_batch_sync(nuslam_batch_t* h)
+{
+    if (!h) return NUSLAM_E_ARG;
+    return sync_status(h);
+}
+
+int nuslam_batch_status(nuslam_batch_t* h, int clear, int* first_bad_filter, int* status_out)
+{
+    if (!h) return NUSLAM_E_ARG;
+    return read_status(h, clear, first_bad_filter, status_out);
+}
+
+int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len)
+{
+    if (!h || !out || out_len < 2 * h->L + 2) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    View v = h->view();
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P, h->tr));
+    if (rc) return rc;
+    rc = launch(h, -1, k_stats, dim3((h->L + 255) / 256), dim3(256), v, (const double*)h->state[h->sidx],
+                (const double*)h->tr, h->stats);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->stats, sizeof(double) * (2 * h->L + 2), hipMemcpyDeviceToHost));
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_profile(nuslam_batch_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_profile(h);
+    if (rc) return rc;
+    for (int k = 0; k < NUSLAM_K_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
+    h->prof = enable != 0;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_profile_read(nuslam_batch_t* h, int kernel, double* total_ms, long long* launches)
+{
+    if (!h || kernel < 0 || kernel >= NUSLAM_K_COUNT) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_profile(h);
+    if (rc) return rc;
+    if (total_ms) *total_ms = h->prof_ms[kernel];
+    if (launches) *launches = h->prof_n[kernel];
+    h->prof_ms[kernel] = 0;
+    h->prof_n[kernel] = 0;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_timer_start(nuslam_batch_t* h)
+{
+    if (!h) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->t0, h->stream));
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_timer_stop(nuslam_batch_t* h, double* elapsed_ms)
+{
+    if (!h || !elapsed_ms) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->t1, h->stream));
+    HIPCHK(hipEventSynchronize(h->t1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->t0, h->t1));
+    *elapsed_ms = ms;
+    return NUSLAM_OK;
+}
+
+// ---- one filter
+int nuslam_ekf_create(const double robot[3], const double* map, int n_landmarks, const double Q[9], const double R[4],
+                      int dtype, int device, nuslam_ekf_t** out)
+{
+    if (!out || !robot || (n_landmarks > 0 && !map)) return NUSLAM_E_ARG;
+    nuslam_batch* core = nullptr;
+    int rc = nuslam_batch_create(1, robot, map, n_landmarks, Q, R, dtype, device, &core);
+    if (rc) return rc;
+    nuslam_ekf* h = new (std::nothrow) nuslam_ekf();
+    if (!h) { free_batch(core); return NUSLAM_E_NOMEM; }
+    h->core = core;
+    *out = h;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_destroy(nuslam_ekf_t* h)
+{
+    if (!h) return NUSLAM_OK;
+    free_batch(h->core);
+    delete h;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
+{
+    if (!src || !out) return NUSLAM_E_ARG;
+    nuslam_batch* s = src->core;
+    nuslam_batch* d = nullptr;
+    int rc = alloc_batch(1, s->n, s->dtype, s->device, &d);
+    if (rc) return rc;
+    memcpy(d->Q, s->Q, sizeof(d->Q));
+    memcpy(d->R, s->R, sizeof(d->R));
+    rc = [&]() -> int {
+        HIPCHK(hipSetDevice(s->device));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        HIPCHK(hipMemcpy(d->state[0], s->state[s->sidx], sizeof(double) * s->ld, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d->state[1], s->state[s->sidx], sizeof(double) * s->ld, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d->ctrl[0], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d->ctrl[1], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d->P, s->P, s->esize() * (size_t)s->p_stride, hipMemcpyDeviceToDevice));
+        return NUSLAM_OK;
+    }();
+    if (rc) { free_batch(d); return rc; }
+    nuslam_ekf* h = new (std::nothrow) nuslam_ekf();
+    if (!h) { free_batch(d); return NUSLAM_E_NOMEM; }
+    h->core = d;
+    *out = h;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out)
+{
+    if (!h || !out) return NUSLAM_E_ARG;
+    *out = h->core;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy)
+{
+    (void)dy;  // Twist2D::dy is never read by the filter (slam_library.cpp:71-148)
+    if (!h) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->core->device));
+    TwistArg tw;
+    tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
+    return do_predict(h->core, tw);
+}
+
+static ObsArg inline_obs(double a, double b, int id, int cartesian)
+{
+    ObsArg o;
+    o.a = nullptr; o.b = nullptr; o.ids = nullptr; o.stride = 0; o.off = 0;
+    o.a0 = a; o.b0 = b; o.id0 = id; o.cartesian = cartesian; o.log_slot = -1;
+    return o;
+}
+
+int nuslam_ekf_update(nuslam_ekf_t* h, double range, double bearing, int id)
+{
+    if (!h) return NUSLAM_E_ARG;
+    if (id < 1 || id > h->core->n) return NUSLAM_E_BOUNDS;
+    HIPCHK(hipSetDevice(h->core->device));
+    return do_update(h->core, inline_obs(range, bearing, id, 0), MODE_FORCE, h->core->n);
+}
+
+int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_out)
+{
+    if (!h || !id_out) return NUSLAM_E_ARG;
+    nuslam_batch* c = h->core;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = do_associate(c, inline_obs(range, bearing, 0, 0));
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(id_out, c->cur_id, sizeof(int), hipMemcpyDeviceToHost));
+    // a full map / singular psi is what the reference reports from inside this very call
+    int st = 0;
+    rc = read_status(c, 1, nullptr, &st);
+    return rc ? rc : st;
+}
+
+int nuslam_ekf_init_landmark(nuslam_ekf_t* h, double range, double bearing, int id)
+{
+    if (!h) return NUSLAM_E_ARG;
+    nuslam_batch* c = h->core;
+    if (id < 1 || id > c->n) return NUSLAM_E_BOUNDS;
+    HIPCHK(hipSetDevice(c->device));
+    View v = c->view();
+    return launch(c, -1, k_init_landmark, dim3(1), dim3(1), v, inline_obs(range, bearing, id, 0), c->state[c->sidx]);
+}
+
+int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, const double* mx, const double* my,
+                    const int* known_ids, int total_landmarks, int* ids_out)
+{
+    (void)dy;
+    if (!h || m < 0 || (m > 0 && (!mx || !my))) return NUSLAM_E_ARG;
+    nuslam_batch* c = h->core;
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_stage(c, m > 0 ? m : 1);
+    if (rc) return rc;
+    if (m > 0) {
+        HIPCHK(hipMemcpyAsync(c->st_mx, mx, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->st_my, my, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+        if (known_ids) HIPCHK(hipMemcpyAsync(c->st_ids, known_ids, sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
+        if (ids_out) HIPCHK(hipMemsetAsync(c->id_log, 0, sizeof(int) * m, c->stream));
+    }
+    TwistArg tw;
+    tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
+    ObsArg o;
+    o.a = c->st_mx; o.b = c->st_my; o.ids = known_ids ? c->st_ids : nullptr;
+    o.stride = 0; o.off = 0; o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
+    rc = do_tick(c, tw, o, m, known_ids != nullptr, total_landmarks);
+    if (rc) return rc;
+    if (ids_out) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (m > 0) HIPCHK(hipMemcpy(ids_out, c->id_log, sizeof(int) * m, hipMemcpyDeviceToHost));
+        return sync_status(c);
+    }
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_len(const nuslam_ekf_t* h, int* len)
+{
+    if (!h || !len) return NUSLAM_E_ARG;
+    *len = h->core->L;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_get_state(nuslam_ekf_t* h, double* out, int len) { return h ? get_state(h->core, 0, out, len) : NUSLAM_E_ARG; }
+int nuslam_ekf_get_cov(nuslam_ekf_t* h, double* out, int ld) { return h ? get_cov(h->core, 0, out, ld) : NUSLAM_E_ARG; }
+int nuslam_ekf_get_seen(nuslam_ekf_t* h, int* seen) { return h ? get_seen(h->core, 0, seen) : NUSLAM_E_ARG; }
+int nuslam_ekf_restore(nuslam_ekf_t* h, const double* state, const double* cov, int ld, int seen)
+{
+    return h ? restore(h->core, 0, state, cov, ld, seen) : NUSLAM_E_ARG;
+}
+int nuslam_ekf_sync(nuslam_ekf_t* h) { return h ? sync_status(h->core) : NUSLAM_E_ARG; }
+int nuslam_ekf_status(nuslam_ekf_t* h, int clear, int* status_out)
+{
+    return h ? read_status(h->core, clear, nullptr, status_out) : NUSLAM_E_ARG;
+}
+
+int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
+{
+    if (!h || !F || ldf < h->core->L) return NUSLAM_E_ARG;
+    nuslam_batch* c = h->core;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = c->esize() * (size_t)c->p_stride;
+    if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));
+    if (!c->wT) {
+        HIPCHK(hipMalloc(&c->wT, bytes));
+        HIPCHK(hipMemsetAsync(c->wT, 0, bytes, c->stream));   // rows [len, ld) of T stay zero: stores are guarded
+    }
+    // stage F into the padded device layout in the covariance's element type
+    HIPCHK(hipMemsetAsync(c->wF, 0, bytes, c->stream));
+    if (c->dtype == NUSLAM_F64) {
+        HIPCHK(hipMemcpy2DAsync(c->wF, sizeof(double) * c->ld, F, sizeof(double) * ldf, sizeof(double) * c->L, c->L,
+                                hipMemcpyHostToDevice, c->stream));
+    } else {
+        std::vector<float> tmp((size_t)c->L * c->L);
+        for (int j = 0; j < c->L; ++j)
+            for (int i = 0; i < c->L; ++i) tmp[i + (size_t)j * c->L] = (float)F[i + (size_t)j * ldf];
+        HIPCHK(hipMemcpy2D(c->wF, sizeof(float) * c->ld, tmp.data(), sizeof(float) * c->L, sizeof(float) * c->L, c->L,
+                           hipMemcpyHostToDevice));
+    }
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    if (c->prof) for (auto& e : ev) { e = get_event(c); if (!e) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; } }
+    int rc = dense_predict_launch(c->dtype, c->L, c->ld, c->wF, c->P, c->wT, c->Q, c->stream, ev);
+    if (c->prof) { c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[0], ev[1]); c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[2], ev[3]); }
+    if (rc) { g_hip_err = "dense_predict_launch failed"; return NUSLAM_E_HIP; }
+    HIPCHK(hipGetLastError());
+    return NUSLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,360 @@
+"""ctypes binding of libnuslam_hip.so (the C ABI of include/nuslam_hip.h) for tests, smoke() and bench.py.
+
+This is a thin harness binding, not a second implementation: every numerical entry point below is one call
+into the HIP library, and loading fails loudly when the library has not been built (there is no CPU fallback).
+The host-language mirror of the reference's C++ class lives in ../cpp/nuslam/slam_library.hpp.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libnuslam_hip.so")
+
+OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
+F64, F32 = 0, 1
+K_PREDICT, K_ASSOCIATE, K_UPDATE_PREPARE, K_UPDATE_SWEEP, K_DENSE_GEMM = range(5)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# every symbol include/nuslam_hip.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+_vpp = C.POINTER(C.c_void_p)
+SYMBOLS = [
+    ("nuslam_strerror", C.c_char_p, [C.c_int]),
+    ("nuslam_last_hip_error", C.c_char_p, []),
+    ("nuslam_abi_version", C.c_int, []),
+    ("nuslam_device_count", C.c_int, [_ip]),
+    ("nuslam_cartesian2polar", C.c_int, [C.c_double, C.c_double, _dp]),
+    ("nuslam_measurement", C.c_int, [_dp, C.c_int, C.c_int, _dp]),
+    ("nuslam_jacobian", C.c_int, [_dp, C.c_int, C.c_int, _dp]),
+    ("nuslam_ekf_create", C.c_int, [_dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, _vpp]),
+    ("nuslam_ekf_destroy", C.c_int, [_vp]),
+    ("nuslam_ekf_clone", C.c_int, [_vp, _vpp]),
+    ("nuslam_ekf_predict", C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
+    ("nuslam_ekf_predict_dense", C.c_int, [_vp, _dp, C.c_int]),
+    ("nuslam_ekf_update", C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    ("nuslam_ekf_associate", C.c_int, [_vp, C.c_double, C.c_double, _ip]),
+    ("nuslam_ekf_init_landmark", C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
+    ("nuslam_ekf_tick", C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp, _ip, C.c_int, _ip]),
+    ("nuslam_ekf_len", C.c_int, [_vp, _ip]),
+    ("nuslam_ekf_get_state", C.c_int, [_vp, _dp, C.c_int]),
+    ("nuslam_ekf_get_cov", C.c_int, [_vp, _dp, C.c_int]),
+    ("nuslam_ekf_get_seen", C.c_int, [_vp, _ip]),
+    ("nuslam_ekf_restore", C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int]),
+    ("nuslam_ekf_sync", C.c_int, [_vp]),
+    ("nuslam_ekf_status", C.c_int, [_vp, C.c_int, _ip]),
+    ("nuslam_batch_create", C.c_int, [C.c_int, _dp, _dp, C.c_int, _dp, _dp, C.c_int, C.c_int, _vpp]),
+    ("nuslam_batch_destroy", C.c_int, [_vp]),
+    ("nuslam_batch_size", C.c_int, [_vp, _ip, _ip]),
+    ("nuslam_batch_load_trace", C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _ip, C.c_int]),
+    ("nuslam_batch_run", C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    ("nuslam_batch_get_state", C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    ("nuslam_batch_get_cov", C.c_int, [_vp, C.c_int, _dp, C.c_int]),
+    ("nuslam_batch_get_seen", C.c_int, [_vp, C.c_int, _ip]),
+    ("nuslam_batch_restore", C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int]),
+    ("nuslam_batch_sync", C.c_int, [_vp]),
+    ("nuslam_batch_status", C.c_int, [_vp, C.c_int, _ip, _ip]),
+    ("nuslam_batch_stats", C.c_int, [_vp, _dp, C.c_int]),
+    ("nuslam_ekf_as_batch", C.c_int, [_vp, _vpp]),
+    ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
+    ("nuslam_batch_timer_start", C.c_int, [_vp]),
+    ("nuslam_batch_timer_stop", C.c_int, [_vp, _dp]),
+]
+
+
+class NuslamError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = "%s: status %d" % (where, code)
+        try:
+            L = lib()
+            msg = "%s: %s" % (where, L.nuslam_strerror(code).decode())
+            if code == E_HIP:
+                msg += " (" + L.nuslam_last_hip_error().decode() + ")"
+        except Exception:
+            pass
+        super().__init__(msg)
+
+
+def build(force=False):
+    """Compile libnuslam_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", PKG_DIR, "-j4", "all"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises if it is missing -- the product path never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libnuslam_hip.so is not built (%s); run __graft_entry__.build() or `make -C %s`"
+                              % (LIB_PATH, PKG_DIR))
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            f = getattr(L, name)       # AttributeError if the library does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _chk(rc, where):
+    if rc != OK:
+        raise NuslamError(rc, where)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def device_count():
+    n = C.c_int(0)
+    lib().nuslam_device_count(C.byref(n))
+    return n.value
+
+
+def cartesian2polar(x, y):
+    out = np.zeros(2)
+    _chk(lib().nuslam_cartesian2polar(x, y, _p(out)), "cartesian2polar")
+    return out
+
+
+def measurement(state, j):
+    s = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.zeros(2)
+    _chk(lib().nuslam_measurement(_p(s), s.size, j, _p(out)), "measurement")
+    return out
+
+
+def jacobian(state, j):
+    s = np.ascontiguousarray(state, dtype=np.float64)
+    H = np.zeros((2, s.size), order="F")
+    _chk(lib().nuslam_jacobian(_p(s), s.size, j, H.ctypes.data_as(_dp)), "jacobian")
+    return H
+
+
+def _qr(Q, R):
+    Qc = np.asfortranarray(np.asarray(Q, dtype=np.float64).reshape(3, 3))
+    Rc = np.asfortranarray(np.asarray(R, dtype=np.float64).reshape(2, 2))
+    return Qc, Rc
+
+
+class Batch:
+    """B independent filters resident on one GPU (nuslam_batch_t)."""
+
+    def __init__(self, n_filters, n_landmarks, Q, R, robot=None, map_state=None, dtype=F64, device=0, _borrow=None):
+        self._own = _borrow is None
+        if _borrow is not None:
+            self._h = _borrow
+        else:
+            Qc, Rc = _qr(Q, R)
+            rb = None if robot is None else np.ascontiguousarray(robot, dtype=np.float64)
+            mp = None if map_state is None else np.ascontiguousarray(map_state, dtype=np.float64)
+            h = C.c_void_p()
+            _chk(lib().nuslam_batch_create(n_filters, _p(rb) if rb is not None else None,
+                                           _p(mp) if mp is not None else None, n_landmarks,
+                                           Qc.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp), dtype, device, C.byref(h)),
+                 "batch_create")
+            self._h = h
+        b, l = C.c_int(), C.c_int()
+        _chk(lib().nuslam_batch_size(self._h, C.byref(b), C.byref(l)), "batch_size")
+        self.B, self.len = b.value, l.value
+        self.n = (self.len - 3) // 2
+
+    def close(self):
+        if getattr(self, "_h", None) and self._own:
+            lib().nuslam_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_trace(self, tw, mx, my, ids=None, bcast=False):
+        """tw: (B|1, T, 2); mx, my: (B|1, T, m); ids: same shape int32 or None (data association)."""
+        tw = np.ascontiguousarray(tw, dtype=np.float64)
+        mx = np.ascontiguousarray(mx, dtype=np.float64)
+        my = np.ascontiguousarray(my, dtype=np.float64)
+        if tw.ndim == 2:
+            tw, mx, my = tw[None], mx[None], my[None]
+            if ids is not None:
+                ids = np.asarray(ids)[None]
+        nb, T = tw.shape[0], tw.shape[1]
+        m = mx.shape[2]
+        assert nb == (1 if bcast else self.B), "trace batch dimension"
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            idp = ids.ctypes.data_as(_ip)
+        _chk(lib().nuslam_batch_load_trace(self._h, T, m, _p(tw), _p(mx), _p(my), idp, 1 if bcast else 0),
+             "batch_load_trace")
+
+    def run(self, t_begin, t_end, total_landmarks=None):
+        _chk(lib().nuslam_batch_run(self._h, t_begin, t_end, self.n if total_landmarks is None else total_landmarks),
+             "batch_run")
+
+    def state(self, b=0):
+        out = np.zeros(self.len)
+        _chk(lib().nuslam_batch_get_state(self._h, b, _p(out), self.len), "batch_get_state")
+        return out
+
+    def cov(self, b=0):
+        out = np.zeros((self.len, self.len), order="F")
+        _chk(lib().nuslam_batch_get_cov(self._h, b, out.ctypes.data_as(_dp), self.len), "batch_get_cov")
+        return out
+
+    def seen(self, b=0):
+        s = C.c_int()
+        _chk(lib().nuslam_batch_get_seen(self._h, b, C.byref(s)), "batch_get_seen")
+        return s.value
+
+    def restore(self, b, state, cov, seen):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        cv = np.asfortranarray(cov, dtype=np.float64)
+        _chk(lib().nuslam_batch_restore(self._h, b, _p(st), cv.ctypes.data_as(_dp), self.len, int(seen)), "batch_restore")
+
+    def sync(self):
+        _chk(lib().nuslam_batch_sync(self._h), "batch_sync")
+
+    def status(self, clear=False):
+        bad, st = C.c_int(), C.c_int()
+        _chk(lib().nuslam_batch_status(self._h, 1 if clear else 0, C.byref(bad), C.byref(st)), "batch_status")
+        return bad.value, st.value
+
+    def stats(self):
+        out = np.zeros(2 * self.len + 2)
+        _chk(lib().nuslam_batch_stats(self._h, _p(out), out.size), "batch_stats")
+        return out
+
+    def profile(self, enable):
+        _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")
+
+    def profile_read(self, kernel):
+        ms, n = C.c_double(), C.c_longlong()
+        _chk(lib().nuslam_batch_profile_read(self._h, kernel, C.byref(ms), C.byref(n)), "batch_profile_read")
+        return ms.value, n.value
+
+    def timer_start(self):
+        _chk(lib().nuslam_batch_timer_start(self._h), "timer_start")
+
+    def timer_stop(self):
+        ms = C.c_double()
+        _chk(lib().nuslam_batch_timer_stop(self._h, C.byref(ms)), "timer_stop")
+        return ms.value
+
+
+class EKF:
+    """One filter (nuslam_ekf_t) -- method for method slam_library::ExtendedKalman (slam_library.hpp:23-113)."""
+
+    def __init__(self, robot, map_state, Q, R, dtype=F64, device=0, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+        else:
+            Qc, Rc = _qr(Q, R)
+            rb = np.ascontiguousarray(robot, dtype=np.float64)
+            mp = np.ascontiguousarray(map_state, dtype=np.float64)
+            h = C.c_void_p()
+            _chk(lib().nuslam_ekf_create(_p(rb), _p(mp) if mp.size else None, mp.size // 2, Qc.ctypes.data_as(_dp),
+                                         Rc.ctypes.data_as(_dp), dtype, device, C.byref(h)), "ekf_create")
+            self._h = h
+        l = C.c_int()
+        _chk(lib().nuslam_ekf_len(self._h, C.byref(l)), "ekf_len")
+        self.len = l.value
+        self.n = (self.len - 3) // 2
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().nuslam_ekf_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clone(self):
+        h = C.c_void_p()
+        _chk(lib().nuslam_ekf_clone(self._h, C.byref(h)), "ekf_clone")
+        return EKF(None, None, None, None, _handle=h)
+
+    def as_batch(self):
+        h = C.c_void_p()
+        _chk(lib().nuslam_ekf_as_batch(self._h, C.byref(h)), "ekf_as_batch")
+        b = Batch(1, self.n, None, None, _borrow=h)
+        b._keep = self
+        return b
+
+    def predict(self, dth, dx, dy=0.0):
+        _chk(lib().nuslam_ekf_predict(self._h, dth, dx, dy), "ekf_predict")
+
+    def predict_dense(self, F):
+        Fc = np.asfortranarray(F, dtype=np.float64)
+        _chk(lib().nuslam_ekf_predict_dense(self._h, Fc.ctypes.data_as(_dp), Fc.shape[0]), "ekf_predict_dense")
+
+    def update(self, r, phi, idx):
+        _chk(lib().nuslam_ekf_update(self._h, r, phi, idx), "ekf_update")
+
+    def associate(self, r, phi):
+        out = C.c_int()
+        _chk(lib().nuslam_ekf_associate(self._h, r, phi, C.byref(out)), "ekf_associate")
+        return out.value
+
+    def init_landmark(self, r, phi, idx):
+        _chk(lib().nuslam_ekf_init_landmark(self._h, r, phi, idx), "ekf_init_landmark")
+
+    def tick(self, tw, mx, my, known_ids=None, total_landmarks=None, want_ids=True):
+        mx = np.ascontiguousarray(mx, dtype=np.float64)
+        my = np.ascontiguousarray(my, dtype=np.float64)
+        m = mx.size
+        kid = None
+        if known_ids is not None:
+            kid = np.ascontiguousarray(known_ids, dtype=np.int32)
+        ids_out = np.zeros(max(m, 1), dtype=np.int32)
+        _chk(lib().nuslam_ekf_tick(self._h, tw[0], tw[1], tw[2] if len(tw) > 2 else 0.0, m, _p(mx), _p(my),
+                                   kid.ctypes.data_as(_ip) if kid is not None else None,
+                                   self.n if total_landmarks is None else total_landmarks,
+                                   ids_out.ctypes.data_as(_ip) if want_ids else None), "ekf_tick")
+        return ids_out[:m].copy() if want_ids else None
+
+    @property
+    def state(self):
+        out = np.zeros(self.len)
+        _chk(lib().nuslam_ekf_get_state(self._h, _p(out), self.len), "ekf_get_state")
+        return out
+
+    @property
+    def cov(self):
+        out = np.zeros((self.len, self.len), order="F")
+        _chk(lib().nuslam_ekf_get_cov(self._h, out.ctypes.data_as(_dp), self.len), "ekf_get_cov")
+        return out
+
+    @property
+    def seen(self):
+        s = C.c_int()
+        _chk(lib().nuslam_ekf_get_seen(self._h, C.byref(s)), "ekf_get_seen")
+        return s.value
+
+    def restore(self, state, cov, seen):
+        st = np.ascontiguousarray(state, dtype=np.float64)
+        cv = np.asfortranarray(cov, dtype=np.float64)
+        _chk(lib().nuslam_ekf_restore(self._h, _p(st), cv.ctypes.data_as(_dp), self.len, int(seen)), "ekf_restore")
+
+    def sync(self):
+        _chk(lib().nuslam_ekf_sync(self._h), "ekf_sync")
+
+    def status(self, clear=False):
+        st = C.c_int()
+        _chk(lib().nuslam_ekf_status(self._h, 1 if clear else 0, C.byref(st)), "ekf_status")
+        return st.value

@@ -76,6 +76,35 @@ def lib():
     return _lib
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask clipped by the cgroup CPU quota (a GPU box hands a
+    16-CPU share of a 256-thread host to each GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    env = os.environ.get("NUSLAM_ORACLE_THREADS")
+    if env:
+        n = int(env)
+    elif n > 32:
+        n = 16      # no quota visible on a big shared host: stay within the documented per-GPU share
+    return n
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 class OracleError(RuntimeError):
     def __init__(self, code):
         super().__init__("oracle status %d" % code)
