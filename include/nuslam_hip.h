@@ -130,10 +130,9 @@ int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do 
 typedef enum {
     NUSLAM_K_PREDICT = 0,
     NUSLAM_K_ASSOCIATE = 1,
-    NUSLAM_K_UPDATE_PREPARE = 2,
-    NUSLAM_K_UPDATE_SWEEP = 3,
-    NUSLAM_K_DENSE_GEMM = 4,
-    NUSLAM_K_COUNT = 5
+    NUSLAM_K_UPDATE = 2,       /* the streaming correction sweep: the HBM-bound kernel */
+    NUSLAM_K_DENSE_GEMM = 3,   /* the two MFMA products of nuslam_ekf_predict_dense */
+    NUSLAM_K_COUNT = 4
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

@@ -158,15 +158,15 @@ static void gemm(int m, int n, int kk, const double* A, int lda, const double* B
             if (nb == 4) {
                 for (int i = 0; i < m; ++i) {
                     const double ai = a[i];
-                    c0[i] = c0[i] + ai * b[0];
-                    c1[i] = c1[i] + ai * b[1];
-                    c2[i] = c2[i] + ai * b[2];
-                    c3[i] = c3[i] + ai * b[3];
+                    c0[i] = fma(ai, b[0], c0[i]);
+                    c1[i] = fma(ai, b[1], c1[i]);
+                    c2[i] = fma(ai, b[2], c2[i]);
+                    c3[i] = fma(ai, b[3], c3[i]);
                 }
             } else {
                 for (int c = 0; c < nb; ++c) {
                     double* cc = C + (size_t)(jb + c) * ldc;
-                    for (int i = 0; i < m; ++i) cc[i] = cc[i] + a[i] * b[c];
+                    for (int i = 0; i < m; ++i) cc[i] = fma(a[i], b[c], cc[i]);
                 }
             }
         }
@@ -403,13 +403,13 @@ static void innovation_cov_structured(const orc_ekf* e, const double Hc[10], int
     for (int q = 0; q < 5; ++q)
         for (int r = 0; r < 2; ++r) {
             double acc = 0.0;
-            for (int q2 = 0; q2 < 5; ++q2) acc = acc + Hc[r + 2 * q2] * e->P[set[q2] + (size_t)set[q] * L];
+            for (int q2 = 0; q2 < 5; ++q2) acc = fma(Hc[r + 2 * q2], e->P[set[q2] + (size_t)set[q] * L], acc);
             HPs[r][q] = acc;
         }
     for (int s2 = 0; s2 < 2; ++s2)
         for (int r = 0; r < 2; ++r) {
             double acc = 0.0;
-            for (int q = 0; q < 5; ++q) acc = acc + HPs[r][q] * Hc[s2 + 2 * q];
+            for (int q = 0; q < 5; ++q) acc = fma(HPs[r][q], Hc[s2 + 2 * q], acc);
             S[r + 2 * s2] = acc + e->R[r + 2 * s2];
         }
 }
@@ -454,8 +454,8 @@ int orc_update(orc_ekf* e, double r, double phi, int id) /* update, :263-282 (tw
         const double dz[2] = { r - zhat[0], phi - zhat[1] };
         for (int i = 0; i < L; ++i) {
             double acc = 0.0;
-            acc = acc + K[i] * dz[0];
-            acc = acc + K[i + (size_t)L] * dz[1];
+            acc = fma(K[i], dz[0], acc);
+            acc = fma(K[i + (size_t)L], dz[1], acc);
             s[i] += acc;
         }
         s[0] = orc_normalize_angle(s[0]);
@@ -481,21 +481,21 @@ int orc_update(orc_ekf* e, double r, double phi, int id) /* update, :263-282 (tw
         double ph[2];
         for (int rr = 0; rr < 2; ++rr) {             /* (P H^T)(i, rr) */
             double acc = 0.0;
-            for (int q = 0; q < 5; ++q) acc = acc + P[i + (size_t)set[q] * L] * Hc[rr + 2 * q];
+            for (int q = 0; q < 5; ++q) acc = fma(P[i + (size_t)set[q] * L], Hc[rr + 2 * q], acc);
             ph[rr] = acc;
         }
         for (int s2 = 0; s2 < 2; ++s2) {             /* K(i, s2) = sum_r PHt(i,r) Sinv(r,s2) */
             double acc = 0.0;
-            acc = acc + ph[0] * Sinv[0 + 2 * s2];
-            acc = acc + ph[1] * Sinv[1 + 2 * s2];
+            acc = fma(ph[0], Sinv[0 + 2 * s2], acc);
+            acc = fma(ph[1], Sinv[1 + 2 * s2], acc);
             K[i + (size_t)s2 * L] = acc;
         }
     }
     const double dz[2] = { r - zhat[0], phi - zhat[1] };
     for (int i = 0; i < L; ++i) {
         double acc = 0.0;
-        acc = acc + K[i] * dz[0];
-        acc = acc + K[i + (size_t)L] * dz[1];
+        acc = fma(K[i], dz[0], acc);
+        acc = fma(K[i + (size_t)L], dz[1], acc);
         s[i] += acc;
     }
     s[0] = orc_normalize_angle(s[0]);
@@ -506,8 +506,8 @@ int orc_update(orc_ekf* e, double r, double phi, int id) /* update, :263-282 (tw
     for (int i = 0; i < L; ++i)
         for (int q = 0; q < 5; ++q) {
             double kh = 0.0;
-            kh = kh + K[i] * Hc[0 + 2 * q];
-            kh = kh + K[i + (size_t)L] * Hc[1 + 2 * q];
+            kh = fma(K[i], Hc[0 + 2 * q], kh);
+            kh = fma(K[i + (size_t)L], Hc[1 + 2 * q], kh);
             Mc[q + 5 * (size_t)i] = (i == set[q] ? 1.0 : 0.0) - kh;
         }
     for (int j = 0; j < L; ++j)
@@ -523,13 +523,13 @@ int orc_update(orc_ekf* e, double r, double phi, int id) /* update, :263-282 (tw
             const double pij = col[i];
             /* ascending k over {0,1,2} U {i} U {c,c+1}; M(i,i) = 1 exactly when i is outside the set */
             double acc = 0.0;
-            acc = acc + m[0] * rw[0];
-            acc = acc + m[1] * rw[1];
-            acc = acc + m[2] * rw[2];
-            if (!in_set && i < c) acc = acc + 1.0 * pij;
-            acc = acc + m[3] * rw[3];
-            acc = acc + m[4] * rw[4];
-            if (!in_set && i > c + 1) acc = acc + 1.0 * pij;
+            acc = fma(m[0], rw[0], acc);
+            acc = fma(m[1], rw[1], acc);
+            acc = fma(m[2], rw[2], acc);
+            if (!in_set && i < c) acc = fma(1.0, pij, acc);
+            acc = fma(m[3], rw[3], acc);
+            acc = fma(m[4], rw[4], acc);
+            if (!in_set && i > c + 1) acc = fma(1.0, pij, acc);
             col[i] = acc;
         }
     }
@@ -582,13 +582,13 @@ int orc_associate(orc_ekf* e, double r, double phi, int* id_out, double* d_out) 
         double w[2];
         for (int s2 = 0; s2 < 2; ++s2) {
             double acc = 0.0;
-            acc = acc + dz[0] * psi_inv[0 + 2 * s2];
-            acc = acc + dz[1] * psi_inv[1 + 2 * s2];
+            acc = fma(dz[0], psi_inv[0 + 2 * s2], acc);
+            acc = fma(dz[1], psi_inv[1 + 2 * s2], acc);
             w[s2] = acc;
         }
         double mahalanobis = 0.0;
-        mahalanobis = mahalanobis + w[0] * dz[0];
-        mahalanobis = mahalanobis + w[1] * dz[1];
+        mahalanobis = fma(w[0], dz[0], mahalanobis);
+        mahalanobis = fma(w[1], dz[1], mahalanobis);
         if (d_out) d_out[k - 1] = mahalanobis;
         if (mahalanobis < min_threshold) { result = k; break; }                                   /* :238-241 */
         else if ((mahalanobis > min_threshold) && (mahalanobis < max_threshold)) { result = -1; break; } /* :243-246 */

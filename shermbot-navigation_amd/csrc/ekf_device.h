@@ -12,9 +12,7 @@ namespace nuslam {
 
 // ctrl words per filter (double-buffered, see View)
 enum { C_SEEN = 0, C_SEEN_CACHED = 1, C_BRK = 2, C_STATUS = 3, C_WORDS = 4 };
-// decision record written by update_prepare, read by update_sweep
-enum { D_SKIP = 0, D_COL = 1, D_WORDS = 4 };
-// how update_prepare resolves the landmark id and whether the slam.cpp decision chain applies
+// how k_update resolves the landmark id and whether the slam.cpp decision chain applies
 enum { MODE_FORCE = 0, MODE_KNOWN = 1, MODE_DA = 2 };
 
 struct View {
@@ -24,7 +22,6 @@ struct View {
     const int* c_in;      // [B][C_WORDS]
     int* c_out;
     long long p_stride;   // elements between consecutive filters' covariance (ld * L)
-    int* dec;             // [B][D_WORDS]
     int* cur_id;          // [B] id resolved by associate
     int* id_log;          // [B][log_stride] resolved id per observation of the current tick (may be null)
     int log_stride;
@@ -87,11 +84,13 @@ __device__ inline void jacobian_compact(double x, double y, double lx, double ly
     const double dy = ly - y;
     const double d = (dx * dx) + (dy * dy);
     const double sd = sqrt(d);
-    Hc[0] = 0.0;       Hc[1] = -1.0;
-    Hc[2] = -dx / sd;  Hc[3] = dy / d;
-    Hc[4] = -dy / sd;  Hc[5] = -dx / d;
-    Hc[6] = dx / sd;   Hc[7] = -dy / d;
-    Hc[8] = dy / sd;   Hc[9] = dx / d;
+    // four divisions; the other four entries are exact negations ((-a)/b == -(a/b) in IEEE arithmetic)
+    const double xs = dx / sd, ys = dy / sd, xd = dx / d, yd = dy / d;
+    Hc[0] = 0.0;  Hc[1] = -1.0;
+    Hc[2] = -xs;  Hc[3] = yd;
+    Hc[4] = -ys;  Hc[5] = -xd;
+    Hc[6] = xs;   Hc[7] = -yd;
+    Hc[8] = ys;   Hc[9] = xd;
 }
 
 // inv() / .i() of a 2x2 as Armadillo 9.800 evaluates it (auxlib::inv_noalias_tinymat; general LU when
@@ -143,7 +142,7 @@ __device__ inline void innovation_cov(const T* __restrict__ Pb, int ld, const in
         for (int r = 0; r < 2; ++r) {
             double acc = 0.0;
 #pragma unroll
-            for (int q2 = 0; q2 < 5; ++q2) acc = acc + Hc[r + 2 * q2] * p[q2];
+            for (int q2 = 0; q2 < 5; ++q2) acc = fma(Hc[r + 2 * q2], p[q2], acc);
             HPs[r][q] = acc;
         }
     }
@@ -153,7 +152,7 @@ __device__ inline void innovation_cov(const T* __restrict__ Pb, int ld, const in
         for (int r = 0; r < 2; ++r) {
             double acc = 0.0;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) acc = acc + HPs[r][q] * Hc[s2 + 2 * q];
+            for (int q = 0; q < 5; ++q) acc = fma(HPs[r][q], Hc[s2 + 2 * q], acc);
             S[r + 2 * s2] = acc + R[r + 2 * s2];
         }
 }

@@ -4,19 +4,19 @@
 //   P      covariance, COLUMN-major like arma::mat, leading dimension ld = roundup(len, 32) elements so that
 //          every column starts on a 128-byte line and 16-byte vector accesses never straddle columns;
 //          rows [len, ld) are zero padding.  Element type T = double or float; all arithmetic is fp64.
+//          Two buffers: update reads one and writes the other (ping-pong), predict works in place.
 //   state  fp64, ld entries, double-buffered (kernels read s_in, write s_out; the host flips the pair).
-//   Mc     5 x ld fp64: the five non-trivial columns of M = I - K H  (columns 0,1,2,c,c+1)      [update scratch]
-//   Rw     5 x ld fp64: rows 0,1,2,c,c+1 of P as they were BEFORE the update                     [update scratch]
+//   ctrl   {seen, seen cached at tick start, break flag, latched status}, double-buffered the same way.
 //
 // Kernels (one stream per handle, launched back to back, no host round trip inside a tick):
-//   k_predict         slam_library.cpp:65-148   O(len) -- A = I + B has two non-zeros, so A P A^T + Qbar only
-//                                               touches rows/cols 1,2 and the 3x3 corner; bit-identical to the
-//                                               dense product evaluated in ascending-k order.
-//   k_associate       slam_library.cpp:188-253  all seen candidates in parallel, min-index reduction.
-//   k_update_prepare  slam_library.cpp:263-276  + the caller's decision chain slam.cpp:295-316: z_hat, H, S,
-//                                               S^-1, K, state correction; emits Mc and Rw.
-//   k_update_sweep    slam_library.cpp:279      P <- (I - K H) P as ONE streaming pass: each element of P is
-//                                               read once and written once (2 len^2 w bytes) -- the HBM-bound kernel.
+//   k_predict    slam_library.cpp:65-148   O(len) -- A = I + B has two non-zeros, so A P A^T + Qbar only touches
+//                                          rows/cols 1,2 and the 3x3 corner; bit-identical to the dense product
+//                                          evaluated in ascending-k order.
+//   k_associate  slam_library.cpp:188-253  all seen candidates in parallel, min-index reduction.
+//   k_update     slam_library.cpp:263-282  + the caller's decision chain slam.cpp:295-316: z_hat, H, S, S^-1, K,
+//                                          state correction and P <- (I - K H) P in ONE streaming pass: each
+//                                          element of P is read once and written once (2 len^2 w bytes) -- the
+//                                          HBM-bound kernel.
 #pragma once
 #include "ekf_device.h"
 
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void k_associate(View v, ObsArg o, const T* __
         if (inv2(psi, psi_inv)) code = 2;                      // psi_k.i() would throw
         else {
             double w0 = 0.0, w1 = 0.0, d = 0.0;                // (dz^T psi^-1) dz, :231
-            w0 = w0 + dz0 * psi_inv[0]; w0 = w0 + dz1 * psi_inv[1];
-            w1 = w1 + dz0 * psi_inv[2]; w1 = w1 + dz1 * psi_inv[3];
-            d = d + w0 * dz0; d = d + w1 * dz1;
+            w0 = fma(dz0, psi_inv[0], w0); w0 = fma(dz1, psi_inv[1], w0);
+            w1 = fma(dz0, psi_inv[2], w1); w1 = fma(dz1, psi_inv[3], w1);
+            d = fma(w0, dz0, d); d = fma(w1, dz1, d);
             if (d < min_threshold) code = 0;                                   // :238
             else if ((d > min_threshold) && (d < max_threshold)) code = 1;     // :243
         }
@@ -222,203 +222,8 @@ __global__ void k_init_landmark(View v, ObsArg o, double* __restrict__ s_cur)
     s[4 + 2 * (id - 1)] = y + r * sin(phi + th);
 }
 
-// ------------------------------------------------------------------------------------------------ update: prepare
-// Thread t owns row t of P (Kalman gain row, state entry, row of M) and column t of P (the gather of the five
-// rows that H touches).  The 2x2 innovation covariance needs only the 5x5 block P[set,set]; every thread
-// recomputes it (25 broadcast loads) so that no inter-workgroup hand-off is needed.
-template <typename T>
-__global__ __launch_bounds__(256) void k_update_prepare(View v, ObsArg o, int mode, int total_landmarks,
-                                                        const T* __restrict__ P, double* __restrict__ Mc,
-                                                        double* __restrict__ Rw)
-{
-    const int b = blockIdx.z;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int ld = v.ld, L = v.L;
-    const double* s = v.s_in + (size_t)b * ld;
-    double* so = v.s_out + (size_t)b * ld;
-    const int* ci = v.c_in + b * C_WORDS;
-    const int seen = ci[C_SEEN], cached = ci[C_SEEN_CACHED], brk = ci[C_BRK];
-    int new_seen = seen, new_brk = brk, new_status = ci[C_STATUS];
-    const bool lead = (t == 0);
-
-    int id;
-    if (mode == MODE_DA) id = v.cur_id[b];
-    else id = o.ids ? o.ids[b * o.stride + o.off] : o.id0;
-
-    // the caller's decision chain, slam.cpp:295-318
-    bool skip = false, init = false;
-    if (mode == MODE_FORCE) {
-        if (id < 1 || id > v.n) { skip = true; if (new_status == 0) new_status = kStatusBounds; }
-    } else if (brk) {
-        skip = true; id = 0;
-    } else if (id > v.n) {
-        skip = true; if (new_status == 0) new_status = kStatusBounds;      // initializeLandmark would index out of bounds
-    } else {
-        if (mode == MODE_KNOWN && id > seen) new_seen = id;                // what associateLandmark would have counted
-        if (id > cached) init = true;                                      // :295-297
-        else if (id < 0) skip = true;                                      // :298-300
-        else if (id > total_landmarks) { skip = true; new_brk = 1; }       // :301-316
-        if (!skip && id < 1) { skip = true; if (new_status == 0) new_status = kStatusBounds; }
-    }
-
-    double r = 0.0, phi = 0.0;
-    int c = 3;
-    double th = 0, x = 0, y = 0, lx = 0, ly = 0;
-    double Hc[10], Sinv[4], dz0 = 0, dz1 = 0;
-    if (!skip) {
-        fetch_obs(o, b, r, phi);
-        c = 3 + 2 * (id - 1);
-        th = s[0]; x = s[1]; y = s[2];
-        if (init) {                                     // initializeLandmark, slam_library.cpp:255-261
-            lx = x + r * cos(phi + th);
-            ly = y + r * sin(phi + th);
-        } else { lx = s[c]; ly = s[c + 1]; }
-        double zr, zb, S[4];
-        measurement(th, x, y, lx, ly, zr, zb);          // :265
-        jacobian_compact(x, y, lx, ly, Hc);             // :268
-        const int set[5] = { 0, 1, 2, c, c + 1 };
-        innovation_cov<T>(P + (size_t)b * v.p_stride, ld, set, Hc, v.R, S);   // H P H^T + R, :270
-        if (inv2(S, Sinv)) { skip = true; if (new_status == 0) new_status = kStatusSingular; }
-        dz0 = r - zr;                                   // :272, bearing innovation not wrapped
-        dz1 = phi - zb;
-    }
-
-    if (lead) {
-        int* co = v.c_out + b * C_WORDS;
-        co[C_SEEN] = new_seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = new_brk; co[C_STATUS] = new_status;
-        int* dec = v.dec + b * D_WORDS;
-        dec[D_SKIP] = skip ? 1 : 0;
-        dec[D_COL] = c;
-        if (v.id_log && o.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot] = id;
-    }
-    if (t >= ld) return;
-    if (skip) {
-        double sv = s[t];
-        if (init && t == c) sv = lx;                    // the landmark was initialised before update() threw
-        if (init && t == c + 1) sv = ly;
-        so[t] = sv;
-        return;
-    }
-
-    const T* Pb = P + (size_t)b * v.p_stride;
-    const int set[5] = { 0, 1, 2, c, c + 1 };
-    if (t < L) {
-        // K = (P H^T) S^-1, row t  (:270)
-        double ph[2];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            double acc = 0.0;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) acc = acc + (double)Pb[(size_t)set[q] * ld + t] * Hc[rr + 2 * q];
-            ph[rr] = acc;
-        }
-        double K[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            double acc = 0.0;
-            acc = acc + ph[0] * Sinv[0 + 2 * s2];
-            acc = acc + ph[1] * Sinv[1 + 2 * s2];
-            K[s2] = acc;
-        }
-        // state += K (z - z_hat); heading re-normalised  (:275-276)
-        double acc = 0.0;
-        acc = acc + K[0] * dz0;
-        acc = acc + K[1] * dz1;
-        double sv = (init && t == c) ? lx : (init && t == c + 1) ? ly : s[t];
-        sv = sv + acc;
-        if (t == 0) sv = normalize_angle(sv);
-        so[t] = sv;
-        // M(t, set[q]) = eye - K H   (:279)
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            double kh = 0.0;
-            kh = kh + K[0] * Hc[0 + 2 * q];
-            kh = kh + K[1] * Hc[1 + 2 * q];
-            Mc[(size_t)b * 5 * ld + (size_t)q * ld + t] = (t == set[q] ? 1.0 : 0.0) - kh;
-        }
-        // rows set[q] of the prior covariance, column t
-#pragma unroll
-        for (int q = 0; q < 5; ++q) Rw[(size_t)b * 5 * ld + (size_t)q * ld + t] = (double)Pb[(size_t)t * ld + set[q]];
-    } else {
-        so[t] = s[t];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            Mc[(size_t)b * 5 * ld + (size_t)q * ld + t] = 0.0;
-            Rw[(size_t)b * 5 * ld + (size_t)q * ld + t] = 0.0;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ update: sweep
-// P'(i,j) = sum_k M(i,k) P(k,j), k ascending over {0,1,2} U {i} U {c,c+1}; M(i,i) = 1 exactly when i is outside
-// the set, so the sum is  M0 R0 + M1 R1 + M2 R2 [+ P(i,j) if 2 < i < c] + Mc Rc + Mc1 Rc1 [+ P(i,j) if i > c+1].
-// One wave owns 64*VEC consecutive rows x CW columns; a lane moves 16 bytes per column (VEC rows), all CW loads
-// are issued before the first use, the column's five R values are wave-uniform (scalar loads).
-template <typename T, int CW>
-__global__ __launch_bounds__(256) void k_update_sweep(View v, T* __restrict__ P, const double* __restrict__ Mc,
-                                                      const double* __restrict__ Rw)
-{
-    typedef Pack16<T> vec_t;
-    constexpr int VEC = 16 / sizeof(T);
-    const int b = blockIdx.z;
-    const int* dec = v.dec + b * D_WORDS;
-    if (dec[D_SKIP]) return;
-    const int c = dec[D_COL];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ld = v.ld, L = v.L;
-    const int row0 = (blockIdx.x * 64 + lane) * VEC;
-    const int j0 = (blockIdx.y * 4 + wave) * CW;
-    if (j0 >= L) return;                 // wave-uniform
-    if (row0 >= ld) return;
-
-    const double* Mb = Mc + (size_t)b * 5 * ld;
-    const double* Rb = Rw + (size_t)b * 5 * ld;
-    double m[5][VEC];
-#pragma unroll
-    for (int q = 0; q < 5; ++q)
-#pragma unroll
-        for (int e = 0; e < VEC; e += 2) {
-            const double2 mm = *reinterpret_cast<const double2*>(Mb + (size_t)q * ld + row0 + e);
-            m[q][e] = mm.x; m[q][e + 1] = mm.y;
-        }
-    bool before[VEC], after[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int i = row0 + e;
-        before[e] = (i > 2) && (i < c);
-        after[e] = (i > c + 1);
-    }
-
-    T* Pw = P + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
-    const int ncol = (L - j0) < CW ? (L - j0) : CW;     // wave-uniform
-    vec_t p[CW];
-#pragma unroll
-    for (int jj = 0; jj < CW; ++jj)
-        if (jj < ncol) p[jj] = *reinterpret_cast<const vec_t*>(Pw + (size_t)jj * ld);
-#pragma unroll
-    for (int jj = 0; jj < CW; ++jj) {
-        if (jj < ncol) {
-            const int j = j0 + jj;
-            const double r0 = Rb[j], r1 = Rb[(size_t)ld + j], r2 = Rb[(size_t)2 * ld + j], r3 = Rb[(size_t)3 * ld + j],
-                         r4 = Rb[(size_t)4 * ld + j];
-            vec_t out;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const double pij = (double)p[jj].v[e];
-                double acc = m[0][e] * r0;
-                acc = acc + m[1][e] * r1;
-                acc = acc + m[2][e] * r2;
-                acc = before[e] ? acc + pij : acc;
-                acc = acc + m[3][e] * r3;
-                acc = acc + m[4][e] * r4;
-                acc = after[e] ? acc + pij : acc;
-                out.v[e] = (T)acc;
-            }
-            *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = out;
-        }
-    }
-}
+// ------------------------------------------------------------------------------------------------ update
+// k_update lives in ekf_update.h (included at the end of this header).
 
 // ------------------------------------------------------------------------------------------------ batch statistics
 // trace(P) per filter: one workgroup per filter, fixed reduction tree (deterministic).
@@ -463,3 +268,5 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 }
 
 } // namespace nuslam
+
+#include "ekf_update.h"

@@ -46,11 +46,9 @@ struct nuslam_batch {
     double* state[2] = { nullptr, nullptr };
     int* ctrl[2] = { nullptr, nullptr };
     int sidx = 0, cidx = 0;
-    void* P = nullptr;
+    void* Pbuf[2] = { nullptr, nullptr };   // covariance ping-pong; Pbuf[pidx] is current
+    int pidx = 0;
     long long p_stride = 0;
-    double* Mc = nullptr;
-    double* Rw = nullptr;
-    int* dec = nullptr;
     int* cur_id = nullptr;
     double* tr = nullptr;      // per-filter trace scratch
     double* stats = nullptr;   // 2L + 2
@@ -58,11 +56,12 @@ struct nuslam_batch {
     // resident trace
     double* tr_tw = nullptr; double* tr_mx = nullptr; double* tr_my = nullptr; int* tr_ids = nullptr;
     int tr_ticks = 0, tr_m = 0, tr_bcast = 0;
+    std::vector<int> h_ids;    // host copy of a broadcast trace's ids: passed inline so k_update needs no id load
     // staging for nuslam_ekf_tick (one filter, m observations)
     double* st_mx = nullptr; double* st_my = nullptr; int* st_ids = nullptr; int* id_log = nullptr;
     int st_cap = 0, log_stride = 0;
-    // dense predict workspaces (element type = dtype)
-    void* wF = nullptr; void* wT = nullptr;
+    // dense predict: staged Jacobian (element type = dtype); the product T = F P goes to the idle P buffer
+    void* wF = nullptr;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[NUSLAM_K_COUNT];
@@ -72,6 +71,8 @@ struct nuslam_batch {
     hipEvent_t t0 = nullptr, t1 = nullptr;
 
     size_t esize() const { return dtype == NUSLAM_F32 ? 4 : 8; }
+    void* P() const { return Pbuf[pidx]; }
+    void* Palt() const { return Pbuf[pidx ^ 1]; }
 
     View view() const
     {
@@ -80,7 +81,7 @@ struct nuslam_batch {
         v.s_in = state[sidx]; v.s_out = state[sidx ^ 1];
         v.c_in = ctrl[cidx]; v.c_out = ctrl[cidx ^ 1];
         v.p_stride = p_stride;
-        v.dec = dec; v.cur_id = cur_id; v.id_log = id_log; v.log_stride = log_stride;
+        v.cur_id = cur_id; v.id_log = id_log; v.log_stride = log_stride;
         memcpy(v.Q, Q, sizeof(Q));
         memcpy(v.R, R, sizeof(R));
         return v;
@@ -149,7 +150,7 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
     View v = h->view();
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, NUSLAM_K_PREDICT, k_predict<T>, grid, block, v, tw, (T*)h->P));
+    DISPATCH_T(h, rc = launch(h, NUSLAM_K_PREDICT, k_predict<T>, grid, block, v, tw, (T*)h->P()));
     if (rc) return rc;
     h->sidx ^= 1;
     h->cidx ^= 1;
@@ -161,7 +162,7 @@ int do_associate(nuslam_batch* h, const ObsArg& o)
     View v = h->view();
     dim3 grid(h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, NUSLAM_K_ASSOCIATE, k_associate<T>, grid, block, v, o, (const T*)h->P));
+    DISPATCH_T(h, rc = launch(h, NUSLAM_K_ASSOCIATE, k_associate<T>, grid, block, v, o, (const T*)h->P()));
     if (rc) return rc;
     h->cidx ^= 1;
     return NUSLAM_OK;
@@ -170,23 +171,22 @@ int do_associate(nuslam_batch* h, const ObsArg& o)
 int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
 {
     View v = h->view();
-    dim3 gridp((h->ld + 255) / 256, 1, h->B), block(256);
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, NUSLAM_K_UPDATE_PREPARE, k_update_prepare<T>, gridp, block, v, o, mode, total,
-                              (const T*)h->P, h->Mc, h->Rw));
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW>, grid, block, v, o, mode, total,
+                               (const T*)h->P(), (T*)h->Palt())));
     if (rc) return rc;
     h->sidx ^= 1;
     h->cidx ^= 1;
-    const int vec = 16 / (int)h->esize();
-    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grids((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B);
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE_SWEEP, k_update_sweep<T, kSweepCW>, grids, block, v, (T*)h->P,
-                               (const double*)h->Mc, (const double*)h->Rw)));
-    return rc;
+    h->pidx ^= 1;
+    return NUSLAM_OK;
 }
 
 // One loop body of slam.cpp:250-319 for every filter of the batch.
-int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total)
+int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
+            const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr)
 {
     int rc = do_predict(h, tw);
     if (rc) return rc;
@@ -194,6 +194,8 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         ObsArg o = base;
         o.off = base.off + i;
         o.log_slot = h->id_log ? i : -1;
+        if (host_ids) { o.ids = nullptr; o.id0 = host_ids[i]; }        // same id for every filter: pass it inline
+        if (host_mx) { o.a = nullptr; o.b = nullptr; o.a0 = host_mx[i]; o.b0 = host_my[i]; }
         if (!known) {
             rc = do_associate(h, o);
             if (rc) return rc;
@@ -209,9 +211,9 @@ void free_batch(nuslam_batch* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->P, h->Mc, h->Rw, h->dec, h->cur_id, h->tr,
+    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->tr,
                      h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->st_mx, h->st_my, h->st_ids, h->id_log,
-                     h->wF, h->wT };
+                     h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int k = 0; k < NUSLAM_K_COUNT; ++k)
@@ -243,14 +245,11 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
         HIPCHK(hipMalloc(&h->state[1], sb));
         HIPCHK(hipMalloc(&h->ctrl[0], sizeof(int) * B * C_WORDS));
         HIPCHK(hipMalloc(&h->ctrl[1], sizeof(int) * B * C_WORDS));
-        HIPCHK(hipMalloc(&h->P, h->esize() * (size_t)B * h->p_stride));
-        HIPCHK(hipMalloc(&h->Mc, sb * 5));
-        HIPCHK(hipMalloc(&h->Rw, sb * 5));
-        HIPCHK(hipMalloc(&h->dec, sizeof(int) * B * D_WORDS));
+        HIPCHK(hipMalloc(&h->Pbuf[0], h->esize() * (size_t)B * h->p_stride));
+        HIPCHK(hipMalloc(&h->Pbuf[1], h->esize() * (size_t)B * h->p_stride));
         HIPCHK(hipMalloc(&h->cur_id, sizeof(int) * B));
         HIPCHK(hipMalloc(&h->tr, sizeof(double) * B));
         HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 2)));
-        HIPCHK(hipMemsetAsync(h->dec, 0, sizeof(int) * B * D_WORDS, h->stream));
         HIPCHK(hipMemsetAsync(h->cur_id, 0, sizeof(int) * B, h->stream));
         HIPCHK(hipEventCreate(&h->t0));
         HIPCHK(hipEventCreate(&h->t1));
@@ -276,18 +275,19 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
         HIPCHK(hipMalloc(&d_map, sizeof(double) * 2 * h->n * (size_t)h->B));
         HIPCHK(hipMemcpyAsync(d_map, map, sizeof(double) * 2 * h->n * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
     }
-    HIPCHK(hipMemsetAsync(h->P, 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
+    HIPCHK(hipMemsetAsync(h->Pbuf[0], 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
+    HIPCHK(hipMemsetAsync(h->Pbuf[1], 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
     View v = h->view();
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, -1, k_init<T>, grid, block, v, (const double*)d_robot, (const double*)d_map, (T*)h->P,
+    DISPATCH_T(h, rc = launch(h, -1, k_init<T>, grid, block, v, (const double*)d_robot, (const double*)d_map, (T*)h->P(),
                               h->state[0], h->state[1], h->ctrl[0], h->ctrl[1]));
     hipError_t e = hipStreamSynchronize(h->stream);
     if (d_robot) (void)hipFree(d_robot);
     if (d_map) (void)hipFree(d_map);
     if (rc) return rc;
     HIPCHK(e);
-    h->sidx = 0; h->cidx = 0;
+    h->sidx = 0; h->cidx = 0; h->pidx = 0;
     return NUSLAM_OK;
 }
 
@@ -323,7 +323,7 @@ int get_cov(nuslam_batch* h, int b, double* out, int ld)
     if (!h || !out || b < 0 || b >= h->B || ld < h->L) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const char* src = (const char*)h->P + h->esize() * (size_t)b * h->p_stride;
+    const char* src = (const char*)h->P() + h->esize() * (size_t)b * h->p_stride;
     if (h->dtype == NUSLAM_F64) {
         HIPCHK(hipMemcpy2D(out, sizeof(double) * ld, src, sizeof(double) * h->ld, sizeof(double) * h->L, h->L,
                            hipMemcpyDeviceToHost));
@@ -354,7 +354,7 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     std::vector<double> s(h->ld, 0.0);
     memcpy(s.data(), state, sizeof(double) * h->L);
     HIPCHK(hipMemcpy(h->state[h->sidx] + (size_t)b * h->ld, s.data(), sizeof(double) * h->ld, hipMemcpyHostToDevice));
-    char* dst = (char*)h->P + h->esize() * (size_t)b * h->p_stride;
+    char* dst = (char*)h->P() + h->esize() * (size_t)b * h->p_stride;
     if (h->dtype == NUSLAM_F64) {
         HIPCHK(hipMemcpy2D(dst, sizeof(double) * h->ld, cov, sizeof(double) * ld, sizeof(double) * h->L, h->L,
                            hipMemcpyHostToDevice));
@@ -517,6 +517,8 @@ int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* t
         }
     }
     h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = bcast ? 1 : 0;
+    h->h_ids.clear();
+    if (ids && m > 0 && (bcast || h->B == 1)) h->h_ids.assign(ids, ids + (size_t)ticks * m);
     return NUSLAM_OK;
 }
 
@@ -536,7 +538,8 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * h->tr_m;
         o.off = (long long)t * h->tr_m;
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
-        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks);
+        const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
+        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks, hid);
     }
     h->id_log = saved_log;
     return rc;
@@ -568,7 +571,7 @@ int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len)
     HIPCHK(hipSetDevice(h->device));
     View v = h->view();
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P, h->tr));
+    DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P(), h->tr));
     if (rc) return rc;
     rc = launch(h, -1, k_stats, dim3((h->L + 255) / 256), dim3(256), v, (const double*)h->state[h->sidx],
                 (const double*)h->tr, h->stats);
@@ -661,7 +664,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
         HIPCHK(hipMemcpy(d->state[1], s->state[s->sidx], sizeof(double) * s->ld, hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy(d->ctrl[0], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy(d->ctrl[1], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(d->P, s->P, s->esize() * (size_t)s->p_stride, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(d->P(), s->P(), s->esize() * (size_t)s->p_stride, hipMemcpyDeviceToDevice));
         return NUSLAM_OK;
     }();
     if (rc) { free_batch(d); return rc; }
@@ -737,20 +740,21 @@ int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, co
     if (!h || m < 0 || (m > 0 && (!mx || !my))) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
     HIPCHK(hipSetDevice(c->device));
-    int rc = ensure_stage(c, m > 0 ? m : 1);
-    if (rc) return rc;
-    if (m > 0) {
-        HIPCHK(hipMemcpyAsync(c->st_mx, mx, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(c->st_my, my, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
-        if (known_ids) HIPCHK(hipMemcpyAsync(c->st_ids, known_ids, sizeof(int) * m, hipMemcpyHostToDevice, c->stream));
-        if (ids_out) HIPCHK(hipMemsetAsync(c->id_log, 0, sizeof(int) * m, c->stream));
+    int* saved_log = c->id_log;
+    if (ids_out && m > 0) {
+        int rc = ensure_stage(c, m);
+        if (rc) return rc;
+        saved_log = c->id_log;
+        HIPCHK(hipMemsetAsync(c->id_log, 0, sizeof(int) * m, c->stream));
+    } else {
+        c->id_log = nullptr;
     }
     TwistArg tw;
     tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
-    ObsArg o;
-    o.a = c->st_mx; o.b = c->st_my; o.ids = known_ids ? c->st_ids : nullptr;
-    o.stride = 0; o.off = 0; o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
-    rc = do_tick(c, tw, o, m, known_ids != nullptr, total_landmarks);
+    // one filter: markers and ids travel inside the kernel arguments, nothing is staged
+    ObsArg o = inline_obs(0.0, 0.0, 0, 1);
+    int rc = do_tick(c, tw, o, m, known_ids != nullptr, total_landmarks, known_ids, mx, my);
+    c->id_log = saved_log;
     if (rc) return rc;
     if (ids_out) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -787,10 +791,6 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = c->esize() * (size_t)c->p_stride;
     if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));
-    if (!c->wT) {
-        HIPCHK(hipMalloc(&c->wT, bytes));
-        HIPCHK(hipMemsetAsync(c->wT, 0, bytes, c->stream));   // rows [len, ld) of T stay zero: stores are guarded
-    }
     // stage F into the padded device layout in the covariance's element type
     HIPCHK(hipMemsetAsync(c->wF, 0, bytes, c->stream));
     if (c->dtype == NUSLAM_F64) {
@@ -800,13 +800,19 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
         std::vector<float> tmp((size_t)c->L * c->L);
         for (int j = 0; j < c->L; ++j)
             for (int i = 0; i < c->L; ++i) tmp[i + (size_t)j * c->L] = (float)F[i + (size_t)j * ldf];
+        HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy2D(c->wF, sizeof(float) * c->ld, tmp.data(), sizeof(float) * c->L, sizeof(float) * c->L, c->L,
                            hipMemcpyHostToDevice));
     }
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    if (c->prof) for (auto& e : ev) { e = get_event(c); if (!e) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; } }
-    int rc = dense_predict_launch(c->dtype, c->L, c->ld, c->wF, c->P, c->wT, c->Q, c->stream, ev);
-    if (c->prof) { c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[0], ev[1]); c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[2], ev[3]); }
+    if (c->prof)
+        for (auto& e : ev) { e = get_event(c); if (!e) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; } }
+    // T = F P into the idle covariance buffer (every row < ld of every column is written), then P = T F^T + Qbar
+    int rc = dense_predict_launch(c->dtype, c->L, c->ld, c->wF, c->P(), c->Palt(), c->Q, c->stream, ev);
+    if (c->prof) {
+        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[0], ev[1]);
+        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[2], ev[3]);
+    }
     if (rc) { g_hip_err = "dense_predict_launch failed"; return NUSLAM_E_HIP; }
     HIPCHK(hipGetLastError());
     return NUSLAM_OK;

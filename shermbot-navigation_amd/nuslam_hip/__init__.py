@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libnuslam_hip.so")
 
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
 F64, F32 = 0, 1
-K_PREDICT, K_ASSOCIATE, K_UPDATE_PREPARE, K_UPDATE_SWEEP, K_DENSE_GEMM = range(5)
+K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM = range(4)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
