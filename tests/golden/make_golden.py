@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Generate the committed fixtures under tests/golden/.  Run in the build container (where /root/reference exists).
+
+  rigid2d_ref.npz   inputs + outputs of the REFERENCE's own rigid2d / DiffDrive code (oracle/_ref/librigid2d_ref.so,
+                    compiled from /root/reference/rigid2d/src/{rigid2d,diff_drive}.cpp by oracle/Makefile).  These
+                    are reference-generated golden vectors: they pin the oracle's rigid2d part and the host C++ mirror.
+  ekf_oracle.npz    traces + per-tick outputs of the ORACLE (oracle/nuslam_oracle.c, dense mode) for the EKF part.
+                    The reference's EKF translation unit cannot be built here (needs Armadillo) and the reference
+                    has no EKF test or recorded trace, so these are regression fixtures of the restatement, NOT
+                    reference outputs ("parity unpinned" for the EKF, see oracle/nuslam_oracle.h).
+Data only: arrays of doubles/ints, no code.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
+import _oracle as O  # noqa: E402
+from nuslam_hip import synth  # noqa: E402
+import ctypes as C  # noqa: E402
+
+_dp = C.POINTER(C.c_double)
+
+
+def p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def rigid2d_ref():
+    assert O.ref_available(), "oracle/_ref/librigid2d_ref.so missing: run `make -C oracle ref` where /root/reference exists"
+    R = O.ref()
+    rng = np.random.default_rng(20261004)
+    K = 64
+    ang = np.concatenate([rng.uniform(-20, 20, K - 6), [0.0, np.pi, -np.pi, 3 * np.pi, 1e-9, -7.5]])
+    norm = np.array([R.ref_normalize_angle(a) for a in ang])
+    tw = rng.normal(size=(K, 3))
+    tw[:8, 0] = 0.0                                   # pure translations: the dth == 0 branch
+    tw[8:12, 1:] = 0.0                                # pure rotations
+    T = np.zeros((K, 4))
+    for i in range(K):
+        R.ref_integrate_twist(p(tw[i]), p(T[i]))
+    frame = rng.normal(size=(K, 3))                   # x, y, rad
+    adj = np.zeros((K, 3))
+    for i in range(K):
+        R.ref_transform_twist(frame[i, 0], frame[i, 1], frame[i, 2], p(tw[i]), p(adj[i]))
+    # DiffDrive: TurtleBot3 constants and the unit-test robot (base 2, radius 1)
+    dd0 = np.array([[0.16, 0.033, 0, 0, 0, 0, 0], [2.0, 1.0, 0, 0, 0, 0, 0]], dtype=np.float64)
+    steps = 40
+    wheel = np.cumsum(rng.uniform(-0.5, 0.8, size=(2, steps, 2)), axis=1)
+    wheel[:, 5] = wheel[:, 4] + 0.25                  # equal increments: exact dth == 0
+    dd_traj = np.zeros((2, steps, 7))
+    dd_tw = np.zeros((2, steps, 3))
+    for r in range(2):
+        dd = dd0[r].copy()
+        for t in range(steps):
+            R.ref_dd_get_twist(p(dd), wheel[r, t, 0], wheel[r, t, 1], p(dd_tw[r, t]))
+            R.ref_dd_step(p(dd), wheel[r, t, 0], wheel[r, t, 1])
+            dd_traj[r, t] = dd
+    conv_tw = rng.normal(size=(K, 3))
+    conv = np.zeros((2, K, 2))
+    for r in range(2):
+        for i in range(K):
+            R.ref_dd_convert_twist(p(dd0[r]), p(conv_tw[i]), p(conv[r, i]))
+    np.savez(os.path.join(HERE, "rigid2d_ref.npz"), ang=ang, norm=norm, tw=tw, T=T, frame=frame, adj=adj,
+             dd0=dd0, wheel=wheel, dd_traj=dd_traj, dd_tw=dd_tw, conv_tw=conv_tw, conv=conv)
+
+
+def ekf_oracle():
+    Q, Rn = synth.Q_DEFAULT, synth.R_DEFAULT
+    out = {}
+    # F1/F2: N = 10 known association, cold start and from the post-initialisation snapshot; F4: includes dth == 0 ticks
+    n, T, m = 10, 40, 10
+    tr = synth.make_trace(n, T, m, straight_every=5)
+    for name, warm in (("cold", False), ("warm", True)):
+        o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, Rn, O.ORC_DENSE)
+        if warm:
+            bx, by, ids = synth.warmup_observations(tr.landmarks)
+            o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=ids)
+            out["n10_warm_snapshot_state"] = o.state.copy()
+            out["n10_warm_snapshot_cov"] = o.cov.copy()
+            out["n10_warm_obs"] = np.stack([bx, by])
+        st = np.zeros((T, o.len)); cv = np.zeros((3, o.len, o.len))
+        for t in range(T):
+            o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
+            st[t] = o.state
+            if t in (0, 1, T - 1):
+                cv[(0, 1, T - 1).index(t)] = o.cov
+        out["n10_%s_state" % name] = st
+        out["n10_%s_cov_0_1_last" % name] = cv
+    out.update(n10_tw=tr.tw, n10_mx=tr.mx, n10_my=tr.my, n10_ids=tr.ids, n10_landmarks=tr.landmarks)
+    # F3: unknown association incl. match / gray-zone / new-landmark outcomes and the per-candidate distances
+    n, T, m = 6, 25, 3
+    lm = np.array([[0.5, 0.5], [-0.5, -0.5], [1.0, 1.0], [-1.0, -1.0], [-0.75, 0.75], [0.75, -0.75]])  # tube_world_params.yaml:4-9
+    tr = synth.make_trace(n + 2, T, m, landmarks=lm, noise_sigma=2e-3)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * (n + 2)), Q, Rn, O.ORC_DENSE)
+    ids = np.zeros((T, m), dtype=np.int32); seen = np.zeros(T, dtype=np.int32); st = np.zeros((T, o.len))
+    dists = np.full((T, m, n + 2), np.nan)
+    for t in range(T):
+        # replay by hand so the per-candidate Mahalanobis distances can be recorded
+        seen_cached = o.seen
+        o.predict(*tr.tw[t])
+        for i in range(m):
+            z = O.cartesian2polar(tr.mx[t, i], tr.my[t, i])
+            k, d = o.associate(z[0], z[1], want_d=True)
+            dists[t, i, :d.size] = d
+            ids[t, i] = k
+            if k > seen_cached:
+                o.init_landmark(z[0], z[1], k)
+            elif k < 0:
+                continue
+            elif k > n + 2:
+                break
+            o.update(z[0], z[1], k)
+        seen[t] = o.seen
+        st[t] = o.state
+    out.update(da_tw=tr.tw, da_mx=tr.mx, da_my=tr.my, da_ids=ids, da_seen=seen, da_state=st, da_dist=dists, da_cov_last=o.cov.copy())
+    np.savez_compressed(os.path.join(HERE, "ekf_oracle.npz"), **out)
+
+
+if __name__ == "__main__":
+    rigid2d_ref()
+    ekf_oracle()
+    print("wrote", os.listdir(HERE))

@@ -1,0 +1,61 @@
+"""No-GPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/nuslam_hip.h
+declares, its pure host helpers agree with the oracle, and it refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import nuslam_hip as nh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nuslam_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nuslam_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(nh.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), "libnuslam_hip.so does not export " + n
+    assert sorted(s[0] for s in nh.SYMBOLS) == names, "python binding table and header disagree"
+    assert nh.lib().nuslam_abi_version() == 1
+
+
+def test_host_helpers_match_oracle():
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        x, y = rng.normal(size=2)
+        assert np.array_equal(nh.cartesian2polar(x, y), O.cartesian2polar(x, y))
+    s = rng.normal(size=3 + 2 * 6)
+    for j in range(1, 7):
+        assert np.array_equal(nh.measurement(s, j), O.measurement(s, j))
+        assert np.array_equal(nh.jacobian(s, j), O.jacobian(s, j))
+    with pytest.raises(nh.NuslamError) as ei:
+        nh.measurement(s, 7)                      # landmark index out of bounds
+    assert ei.value.code == nh.E_BOUNDS
+
+
+def test_no_cpu_fallback():
+    if nh.device_count() > 0:
+        pytest.skip("a GPU is visible: the refusal path is for device-less hosts")
+    with pytest.raises(nh.NuslamError) as ei:
+        nh.EKF(np.zeros(3), np.zeros(4), np.eye(3), np.eye(2))
+    assert ei.value.code == nh.E_NODEV
+    with pytest.raises(nh.NuslamError):
+        nh.Batch(2, 3, np.eye(3), np.eye(2))
+
+
+def test_error_strings():
+    L = nh.lib()
+    for code in range(7):
+        assert L.nuslam_strerror(code)
+    assert b"logic_error" in L.nuslam_strerror(nh.E_BOUNDS)
+    assert b"runtime_error" in L.nuslam_strerror(nh.E_SINGULAR)
