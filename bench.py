@@ -156,16 +156,12 @@ def main():
     if st != 0:
         raise RuntimeError("device status %d on filter %d" % (st, bad))
 
+    from nuslam_hip import dist as nd
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        # the batch reduction over xGMI (RCCL): Monte-Carlo statistics of all replicas, gathered and summed in rank order
-        stats = torch.from_numpy(bt.stats()).cuda()
-        gathered = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        total = torch.stack(gathered).sum(0)
-        n_filters_total = int(total[-1].item())
+        dt = nd.max_over_ranks(dt, device="cuda")
+        # the batch reduction over xGMI (RCCL): Monte-Carlo statistics of all trials, gathered and summed in rank order
+        total, _ = nd.reduce_stats(bt.stats(), device="cuda")
+        n_filters_total = int(total[-1])
     else:
         n_filters_total = B
 

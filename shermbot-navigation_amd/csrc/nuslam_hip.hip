@@ -791,16 +791,17 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = c->esize() * (size_t)c->p_stride;
     if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));
-    // stage F into the padded device layout in the covariance's element type
+    // stage F into the padded device layout in the covariance's element type.  F is caller-owned pageable host
+    // memory and may be released as soon as this call returns, so the copy is synchronous.
     HIPCHK(hipMemsetAsync(c->wF, 0, bytes, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (c->dtype == NUSLAM_F64) {
-        HIPCHK(hipMemcpy2DAsync(c->wF, sizeof(double) * c->ld, F, sizeof(double) * ldf, sizeof(double) * c->L, c->L,
-                                hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpy2D(c->wF, sizeof(double) * c->ld, F, sizeof(double) * ldf, sizeof(double) * c->L, c->L,
+                           hipMemcpyHostToDevice));
     } else {
         std::vector<float> tmp((size_t)c->L * c->L);
         for (int j = 0; j < c->L; ++j)
             for (int i = 0; i < c->L; ++i) tmp[i + (size_t)j * c->L] = (float)F[i + (size_t)j * ldf];
-        HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy2D(c->wF, sizeof(float) * c->ld, tmp.data(), sizeof(float) * c->L, sizeof(float) * c->L, c->L,
                            hipMemcpyHostToDevice));
     }

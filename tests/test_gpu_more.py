@@ -1,0 +1,181 @@
+"""GPU parity, part 2: dense MFMA predict, fp32 storage, per-filter batch traces, the C++ host mirror."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from nuslam_hip import synth
+
+pytestmark = pytest.mark.gpu
+Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def warm_oracle(n, mode=O.ORC_STRUCTURED, seed=12345):
+    lm = synth.make_landmarks(n, seed)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, mode)
+    bx, by, ids = synth.warmup_observations(lm, seed=seed)
+    o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=ids)
+    return o, lm
+
+
+# ------------------------------------------------------------------ dense predict (MFMA)
+@pytest.mark.parametrize("n", [3, 30, 100])
+def test_dense_predict_identity_and_permutation_exact(hip, n):
+    """F = I leaves P + Qbar exactly; a permutation F only moves entries: both are exact in any summation order,
+    and P is not symmetric to the last bit, so a transposed operand or a swapped C/D lane map cannot hide."""
+    o, _ = warm_oracle(n)
+    L = o.len
+    rng = np.random.default_rng(5)
+    P0 = o.cov.copy() + 1e-3 * rng.normal(size=(L, L))      # clearly asymmetric
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    g.restore(o.state, P0, n)
+    g.predict_dense(np.eye(L))
+    Qb = np.zeros((L, L)); Qb[:3, :3] = Q
+    assert np.array_equal(g.cov, P0 + Qb)
+    perm = rng.permutation(L)
+    F = np.zeros((L, L)); F[np.arange(L), perm] = 1.0
+    g.restore(o.state, P0, n)
+    g.predict_dense(F)
+    assert np.array_equal(g.cov, P0[np.ix_(perm, perm)] + Qb)
+    assert np.array_equal(g.state, o.state)                  # the state is not touched
+
+
+@pytest.mark.parametrize("n", [10, 100, 333])
+def test_dense_predict_matches_oracle_fp64(hip, n):
+    o, _ = warm_oracle(n, O.ORC_DENSE)
+    L = o.len
+    rng = np.random.default_rng(11)
+    F = np.eye(L) + 0.05 * rng.normal(size=(L, L)) / np.sqrt(L)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    g.restore(o.state, o.cov, n)
+    O.set_threads(O.usable_cpus())
+    o.predict_dense(F)
+    O.set_threads(1)
+    g.predict_dense(F)
+    err = np.abs(g.cov - o.cov).max() / np.abs(o.cov).max()
+    print("dense predict fp64 n=%d: max|dP|/max|P| = %.2e" % (n, err))
+    assert err < 1e-13      # same products, MFMA k-order instead of ascending k
+
+
+def test_dense_predict_fp32(hip):
+    """fp32 storage + exact-f32 MFMA (v_mfma_f32_32x32x2_f32): tolerance stated against the fp64 oracle."""
+    n = 100
+    o, _ = warm_oracle(n, O.ORC_DENSE)
+    L = o.len
+    rng = np.random.default_rng(12)
+    F = np.eye(L) + 0.05 * rng.normal(size=(L, L)) / np.sqrt(L)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=hip.F32)
+    g.restore(o.state, o.cov, n)
+    o.predict_dense(F)
+    g.predict_dense(F)
+    err = np.abs(g.cov - o.cov).max() / np.abs(o.cov).max()
+    print("dense predict fp32: max|dP|/max|P| = %.2e" % err)
+    assert err < 5e-6
+
+
+# ------------------------------------------------------------------ fp32 covariance storage
+def test_fp32_storage_trajectory(hip):
+    """BASELINE config 3 stores P in fp32 (state and all O(len) arithmetic stay fp64).  Against the fp64 oracle
+    from a warm snapshot: state 1e-3, covariance 1e-3 of max|P| (1e-6 is not reachable in fp32)."""
+    n, T, m = 40, 10, 8
+    o, lm = warm_oracle(n)
+    tr = synth.make_trace(n, T, m, landmarks=lm)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=hip.F32)
+    g.restore(o.state, o.cov, n)
+    for t in range(T):
+        o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
+        g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+    es = np.abs(g.state - o.state).max()
+    ep = np.abs(g.cov - o.cov).max() / np.abs(o.cov).max()
+    print("fp32 storage: |dstate| %.2e, |dP|/max|P| %.2e" % (es, ep))
+    assert es < 1e-3 and ep < 1e-3
+
+
+def test_fp32_cold_start_initialises(hip):
+    """INT_MAX on the diagonal rounds to 2^31 in fp32; the first update must still produce a finite, small variance."""
+    n = 6
+    tr = synth.make_trace(n, 2, n)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=hip.F32)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    for t in range(2):
+        g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+        o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
+    assert np.isfinite(g.cov).all() and np.diag(g.cov).max() < 1.0
+    assert np.abs(g.state - o.state).max() < 1e-2
+
+
+# ------------------------------------------------------------------ batch with per-filter traces
+def test_batch_per_filter_traces(hip):
+    """Monte-Carlo trials: every filter gets its own trace; filter b must equal a single filter fed trace b,
+    bit for bit, and the batch statistics must be the filter-ordered sums."""
+    n, m, T, B = 12, 5, 5, 4
+    traces = [synth.make_trace(n, T, m, seed=100 + b) for b in range(B)]
+    bt = hip.Batch(B, n, Q, R)
+    tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces])
+    my = np.stack([t.my for t in traces]); ids = np.stack([t.ids for t in traces])
+    bt.load_trace(tw, mx, my, ids)
+    bt.run(0, T)
+    states = []
+    for b in range(B):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+        for t in range(T):
+            g.tick(traces[b].tw[t], traces[b].mx[t], traces[b].my[t], known_ids=traces[b].ids[t], want_ids=False)
+        assert np.array_equal(bt.state(b), g.state) and np.array_equal(bt.cov(b), g.cov) and bt.seen(b) == g.seen
+        states.append(g.state)
+    st = bt.stats()
+    acc = np.zeros(g.len); acc2 = np.zeros(g.len)
+    for s in states:
+        acc = acc + s
+        acc2 = acc2 + s * s
+    assert np.array_equal(st[:g.len], acc) and np.array_equal(st[g.len:2 * g.len], acc2)
+    assert bt.status() == (-1, 0)
+
+
+def test_batch_data_association(hip):
+    n, m, T, B = 8, 3, 12, 3
+    traces = [synth.make_trace(n, T, m, seed=200 + b, noise_sigma=1e-3) for b in range(B)]
+    bt = hip.Batch(B, n, Q, R)
+    bt.load_trace(np.stack([t.tw[:, :2] for t in traces]), np.stack([t.mx for t in traces]),
+                  np.stack([t.my for t in traces]), None)
+    bt.run(0, T)
+    for b in range(B):
+        o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
+        for t in range(T):
+            o.tick(tw=traces[b].tw[t], mx=traces[b].mx[t], my=traces[b].my[t])
+        assert bt.seen(b) == o.seen
+        assert np.abs(bt.state(b) - o.state).max() < 1e-4
+
+
+# ------------------------------------------------------------------ the C++ host mirror
+def test_cpp_host_mirror_replays_slam_loop(hip):
+    """cpp/tests/replay_slam_loop drives slam_library::ExtendedKalman (C++ class over the C ABI) and
+    rigid2d::DiffDrive (host C++) exactly like nuslam/src/slam.cpp:231-319, with unknown data association."""
+    exe = os.path.join(ROOT, "shermbot-navigation_amd", "cpp", "tests", "replay_slam_loop")
+    assert os.path.exists(exe), "build it first: make -C shermbot-navigation_amd/cpp"
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ekf_oracle.npz"))
+    lm = np.array([[0.5, 0.5], [-0.5, -0.5], [1.0, 1.0], [-1.0, -1.0], [-0.75, 0.75], [0.75, -0.75]])
+    n, T, m = 8, 25, 3
+    tr = synth.make_trace(n, T, m, landmarks=lm, noise_sigma=2e-3)
+    assert np.array_equal(tr.mx, g["da_mx"])               # the same trace the DA fixture was made from
+    lines = ["%d %d %d %d %.17g %.17g" % (n, n, T, m, synth.WHEEL_BASE, synth.WHEEL_RADIUS)]
+    for t in range(T):
+        lines.append("%.17g %.17g " % (tr.thL[t], tr.thR[t]) + " ".join("%.17g %.17g" % (tr.mx[t, i], tr.my[t, i]) for i in range(m)))
+    out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    # oracle, driven from the same wheel angles
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
+    dd = O.dd_new(synth.WHEEL_BASE, synth.WHEEL_RADIUS)
+    rows = [l.split() for l in out.stdout.splitlines()]
+    trows = [r for r in rows if r[0] == "T"]
+    for t in range(T):
+        ids = o.tick(dd=dd, thL=tr.thL[t], thR=tr.thR[t], mx=tr.mx[t], my=tr.my[t])
+        assert np.array_equal(ids, g["da_ids"][t])
+        assert int(trows[t][1]) == o.seen
+        assert np.allclose([float(x) for x in trows[t][2:5]], o.state[:3], atol=1e-4, rtol=0)
+    S = np.array([float(x) for x in next(r for r in rows if r[0] == "S")[1:]])
+    P = np.array([float(x) for x in next(r for r in rows if r[0] == "P")[1:]]).reshape((o.len, o.len), order="F")
+    assert np.allclose(S, o.state, atol=1e-4, rtol=0)
+    assert np.linalg.norm(P - o.cov) / np.linalg.norm(o.cov) < 1e-4
