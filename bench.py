@@ -104,7 +104,10 @@ def main():
 
     # ---- synthetic input (seeded; Monte-Carlo replica r uses seed 12345 + r), made resident in HBM
     seed = 12345 + rank
-    tr = synth.make_trace(n, W + 2 * K, m, seed=seed)
+    # data association needs one free slot: associateLandmark writes a hypothetical landmark at index seen+1 and
+    # indexes out of bounds on a full map (slam_library.cpp:206-207), so the world holds n-1 landmarks there
+    n_world = n if known else n - 1
+    tr = synth.make_trace(n_world, W + 2 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
     bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed)
     Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
 
@@ -196,8 +199,14 @@ def main():
         per_launch_bytes = 2.0 * L * L * w * B           # read + write every P entry once, per filter
         avg_s = 1e-3 * sweep_ms / sweep_n
         ach = per_launch_bytes / avg_s / 1e9
+        # HBM bytes per launch from the PMC counters: a committed rocprofv3 --pmc measurement of this very workload
+        # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction); null for others
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "ekf1000_pmc_hbm_traffic.json")
+        if args.workload == "ekf1000" and n == 1000 and dtype == nh.F64 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["per_launch_bytes"]["hbm_traffic"]
         out["roofline"] = {"bound": "hbm", "kernel": "k_update", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "avg_launch_us": 1e6 * avg_s, "launches": sweep_n,
                            "algorithmic_bytes_per_launch": per_launch_bytes}
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
