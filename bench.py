@@ -11,6 +11,8 @@ Workloads
   batch     (BASELINE configs[3]) --filters independent EKFs of N = 200 landmarks per GPU, one launch per
             kernel for the whole batch.
   da1000    (BASELINE configs[4]) as ekf1000 with unknown data association (associateLandmark per marker).
+  ekf5000   (BASELINE configs[2]) one EKF, N = 5000, fp32 covariance, every predict propagates P with a resident
+            dense Jacobian on the matrix cores (F P F^T, 4 L^3 flop) -- the MFMA-bound configuration.
 `value` = corrections (EKF updates) per second over all ranks = ranks * filters * m * steps / seconds.
 
 Extra objects: "roofline" for the dominant kernel (k_update; algorithmic bytes 2*L^2*w per launch per
@@ -37,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="ekf1000", choices=["ekf1000", "batch", "da1000"])
+    ap.add_argument("--workload", default="ekf1000", choices=["ekf1000", "batch", "da1000", "ekf5000"])
     ap.add_argument("--landmarks", type=int, default=None)
     ap.add_argument("--filters", type=int, default=None, help="filters per GPU (batch workload; default 1024/gpus)")
     ap.add_argument("--m", type=int, default=16, help="corrections per tick")
@@ -89,13 +91,17 @@ def main():
     import nuslam_hip as nh
     from nuslam_hip import synth
 
+    if args.workload == "ekf5000":
+        args.dtype = "f32"
+        if args.steps == 200 and args.warmup == 20:
+            args.steps, args.warmup = 5, 1          # a tick is ~45 ms here
     dtype = nh.F64 if args.dtype == "f64" else nh.F32
     w = 8 if dtype == nh.F64 else 4
     if args.workload == "batch":
         n = args.landmarks or 200
         B = args.filters or max(1, 1024 // world)
     else:
-        n = args.landmarks or 1000
+        n = args.landmarks or (5000 if args.workload == "ekf5000" else 1000)
         B = 1
     m = min(args.m, n)
     L = 3 + 2 * n
@@ -110,13 +116,30 @@ def main():
     tr = synth.make_trace(n_world, W + 2 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
     bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed)
     Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+    if not known:
+        # With the node's Q = diag(0.1) every prediction inflates the pose covariance so much that an earlier-indexed
+        # neighbour lands in the (0.01, 60) gray zone and associateLandmark returns -1 before reaching the true
+        # landmark (slam_library.cpp:243-246): almost nothing is ever corrected.  The association workload uses the
+        # well-conditioned Q = diag(1e-4) of SURVEY section 8d so that matches (and corrections) actually happen.
+        Q = np.diag([1e-4, 1e-4, 1e-4])
 
     if B == 1:
         ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
         bt = ekf.as_batch()
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
         ekf.sync()
-        warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and args.cpu_seconds > 0) else None
+        warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None
+        if args.workload == "ekf5000":
+            # the reference's own A = I + B for the first twist, handed over as a DENSE Jacobian and kept resident
+            dth, dx = tr.tw[0][0], tr.tw[0][1]
+            F = np.eye(L)
+            F[1, 0] = -(dx / dth) * np.cos(dth) + (dx / dth) * np.cos(2 * dth)
+            F[2, 0] = -(dx / dth) * np.sin(dth) + (dx / dth) * np.sin(2 * dth)
+            s0, P0, sn = ekf.state, ekf.cov, ekf.seen
+            ekf.predict_dense(F)
+            ekf.restore(s0, P0, sn)
+            ekf.use_dense_predict(True)
+            del F, P0
     else:
         bt = nh.Batch(B, n, Q, R, dtype=dtype, device=dev)
         # initialise every filter's map with one resident warm-up tick of n observations
@@ -154,6 +177,7 @@ def main():
     sweep_ms, sweep_n = bt.profile_read(nh.K_UPDATE)
     pred_ms, pred_n = bt.profile_read(nh.K_PREDICT)
     asso_ms, asso_n = bt.profile_read(nh.K_ASSOCIATE)
+    gemm_ms, gemm_n = bt.profile_read(nh.K_DENSE_GEMM)
     bt.profile(False)
     bad, st = bt.status()
     if st != 0:
@@ -189,10 +213,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": {"ekf1000": "single EKF per GPU, known association (BASELINE configs[1])",
                                 "batch": "batch of independent EKFs per GPU (BASELINE configs[3])",
-                                "da1000": "single EKF per GPU, unknown data association (BASELINE configs[4])"}[args.workload],
+                                "da1000": "single EKF per GPU, unknown data association (BASELINE configs[4])",
+                                "ekf5000": "single EKF per GPU, fp32, dense MFMA F P F^T predict (BASELINE configs[2])"}[args.workload],
                    "landmarks": n, "state_len": L, "filters_per_gpu": B, "filters_total": n_filters_total,
                    "updates_per_step": m, "parallelism": "replicas x%d" % world if B == 1 else "filters sharded x%d" % world,
-                   "kernel_events_in_timed_region": in_region},
+                   "kernel_events_in_timed_region": in_region, "Q_diag": float(Q[0, 0]), "R_diag": float(R[0, 0])},
         "ticks_per_s": float(world) * B * K / dt,
     }
     if use_events and sweep_n:
@@ -212,6 +237,15 @@ def main():
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
+    if gemm_n:
+        flop = 2.0 * L ** 3                                    # one of the two products of F P F^T
+        avg_s = 1e-3 * gemm_ms / gemm_n
+        peak = 157.3 if dtype == nh.F32 else 78.6              # MI355X_MICROARCH.md: dense f32 / f64 matrix peak, TFLOP/s
+        out["roofline_hbm_kernel"] = out.get("roofline")
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm (F P, then T F^T + Qbar)", "achieved": flop / avg_s / 1e12,
+                           "peak": peak, "unit": "TFLOP/s", "frac": flop / avg_s / 1e12 / peak, "traffic": None,
+                           "avg_launch_us": 1e6 * avg_s, "launches": gemm_n, "algorithmic_flop_per_launch": flop}
+        out["kernel_us"]["dense_gemm"] = 1e6 * avg_s
     if warm_state is not None and args.cpu_seconds > 0 and args.workload == "ekf1000":
         cb, _ = cpu_baseline(n, m, synth.make_trace(n, W + 2 * K, m, seed=12345), args.cpu_seconds, warm_state)
         out["cpu_baseline"] = cb

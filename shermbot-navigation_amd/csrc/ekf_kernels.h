@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void k_init(View v, const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ predict
-template <typename T>
+// STATE_ONLY: predictEstimate + the tick bookkeeping only; the covariance is then propagated by the dense MFMA
+// path (nuslam_ekf_predict_dense) instead of the two-non-zero shortcut below.
+template <typename T, bool STATE_ONLY>
 __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restrict__ P)
 {
     const int b = blockIdx.z;
@@ -82,6 +84,14 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
     }
     if (t < v.ld) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
 
+    if (STATE_ONLY) {
+        if (t == 0) {
+            const int* ci = v.c_in + b * C_WORDS;
+            int* co = v.c_out + b * C_WORDS;
+            co[C_SEEN] = ci[C_SEEN]; co[C_SEEN_CACHED] = ci[C_SEEN]; co[C_BRK] = 0; co[C_STATUS] = ci[C_STATUS];
+        }
+        return;
+    }
     // propagateUncertainty, slam_library.cpp:96-108:  T = A P (rows 1,2),  U = T A^T (cols 1,2),  + Qbar
     T* Pb = P + (size_t)b * v.p_stride;
     const int ld = v.ld;

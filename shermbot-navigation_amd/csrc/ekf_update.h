@@ -84,10 +84,13 @@ __device__ inline double lane_bcast(double val, int src)
 // before the first wait, as vector loads: the wave-uniform inputs (pose, landmark, the 5x5 block, the 5 x CW
 // prior-row strip) are fetched one element per lane and broadcast with v_readlane instead of chains of dependent
 // scalar loads.  With the landmark id passed inline every address depends only on kernel arguments.
-template <typename T, int CW>
-__global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int mode, int total_landmarks,
+// MODE and INLINE_ID are compile-time so that the known-association fast path (id inside the kernel arguments)
+// contains no load at all in front of the burst.
+template <typename T, int CW, int MODE, bool INLINE_ID>
+__global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_landmarks,
                                                 const T* __restrict__ Pin, T* __restrict__ Pout)
 {
+    constexpr int mode = MODE;
     static_assert(CW == 16, "the prior-row strip is fetched as 16 columns x {3, 2} rows per vector load");
     typedef Pack16<T> vec_t;
     constexpr int VEC = 16 / sizeof(T);
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int mode, int 
     // whenever the decision below keeps the update.
     const int* ci = v.c_in + b * C_WORDS;
     const int seen = ci[C_SEEN], cached = ci[C_SEEN_CACHED], brk = ci[C_BRK], status0 = ci[C_STATUS];
-    const int id_raw = (mode == MODE_DA) ? v.cur_id[b] : (o.ids ? o.ids[b * o.stride + o.off] : o.id0);
+    const int id_raw = (MODE == MODE_DA) ? v.cur_id[b] : (INLINE_ID ? o.id0 : o.ids[b * o.stride + o.off]);
     const int cg = (id_raw >= 1 && id_raw <= v.n) ? 3 + 2 * (id_raw - 1) : 3;
     const double* s = v.s_in + (size_t)b * ld;
     const T* Pb = Pin + (size_t)b * v.p_stride;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int mode, int 
 
     // (4) this lane's rows: K(i,:) = (P H^T)(i,:) S^-1 and M(i, set[q]) = eye - K H      (:270, :279)
     double m[5][VEC];
-    bool before[VEC], after[VEC];
+    double before[VEC], after[VEC];       // 1.0 where P(i,j) itself enters the sum before / after the landmark terms
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const int i = row0 + e;
@@ -258,8 +261,8 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int mode, int 
             kh = fma(K[1], Hc[1 + 2 * q], kh);
             m[q][e] = (i == set[q] ? 1.0 : 0.0) - kh;
         }
-        before[e] = (i > 2) && (i < c);
-        after[e] = (i > c + 1);
+        before[e] = ((i > 2) && (i < c)) ? 1.0 : 0.0;
+        after[e] = (i > c + 1) ? 1.0 : 0.0;
         if (owns_state && rows_ok) {
             // state += K (z - z_hat); heading re-normalised  (:275-276).  Rows [len, ld) are zero padding: K = 0.
             double acc = 0.0;
@@ -284,10 +287,10 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int mode, int 
             double acc = m[0][e] * r0;
             acc = fma(m[1][e], r1, acc);
             acc = fma(m[2][e], r2, acc);
-            acc = before[e] ? acc + pij : acc;
+            acc = fma(before[e], pij, acc);               // + 1.0 * P(i,j) or + 0.0 * P(i,j): exact either way
             acc = fma(m[3][e], r3, acc);
             acc = fma(m[4][e], r4, acc);
-            acc = after[e] ? acc + pij : acc;
+            acc = fma(after[e], pij, acc);
             out.v[e] = (T)acc;
         }
         if (jj < ncol && rows_ok) *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = out;

@@ -62,6 +62,8 @@ struct nuslam_batch {
     int st_cap = 0, log_stride = 0;
     // dense predict: staged Jacobian (element type = dtype); the product T = F P goes to the idle P buffer
     void* wF = nullptr;
+    bool f_staged = false;
+    bool dense_predict = false;   // do_predict: state-only kernel + the two MFMA products with the staged Jacobian
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[NUSLAM_K_COUNT];
@@ -145,12 +147,33 @@ int drain_profile(nuslam_batch* h)
         else { typedef double T; CALL; }                      \
     } while (0)
 
+int launch_dense(nuslam_batch* c)
+{
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    if (c->prof)
+        for (auto& e : ev) { e = get_event(c); if (!e) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; } }
+    // T = F P into the idle covariance buffer (every row < len of every column is written), then P = T F^T + Qbar
+    int rc = dense_predict_launch(c->dtype, c->L, c->ld, c->wF, c->P(), c->Palt(), c->Q, c->stream, ev);
+    if (c->prof) {
+        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[0], ev[1]);
+        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[2], ev[3]);
+    }
+    if (rc) { g_hip_err = "dense_predict_launch failed"; return NUSLAM_E_HIP; }
+    HIPCHK(hipGetLastError());
+    return NUSLAM_OK;
+}
+
 int do_predict(nuslam_batch* h, const TwistArg& tw)
 {
     View v = h->view();
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, NUSLAM_K_PREDICT, k_predict<T>, grid, block, v, tw, (T*)h->P()));
+    if (h->dense_predict) {
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, true>, grid, block, v, tw, (T*)h->P())));
+        if (!rc) rc = launch_dense(h);
+    } else {
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, v, tw, (T*)h->P())));
+    }
     if (rc) return rc;
     h->sidx ^= 1;
     h->cidx ^= 1;
@@ -175,8 +198,14 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW>, grid, block, v, o, mode, total,
-                               (const T*)h->P(), (T*)h->Palt())));
+    const bool inl = (o.ids == nullptr);
+#define LAUNCH_UPDATE(MODE_, INL_)                                                                              \
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW, MODE_, INL_>, grid, block, v, o, total, \
+                               (const T*)h->P(), (T*)h->Palt())))
+    if (mode == MODE_DA) LAUNCH_UPDATE(MODE_DA, true);
+    else if (mode == MODE_FORCE) { if (inl) LAUNCH_UPDATE(MODE_FORCE, true); else LAUNCH_UPDATE(MODE_FORCE, false); }
+    else { if (inl) LAUNCH_UPDATE(MODE_KNOWN, true); else LAUNCH_UPDATE(MODE_KNOWN, false); }
+#undef LAUNCH_UPDATE
     if (rc) return rc;
     h->sidx ^= 1;
     h->cidx ^= 1;
@@ -786,36 +815,37 @@ int nuslam_ekf_status(nuslam_ekf_t* h, int clear, int* status_out)
 
 int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
 {
-    if (!h || !F || ldf < h->core->L) return NUSLAM_E_ARG;
+    if (!h || (F && ldf < h->core->L)) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
+    if (!F && !c->f_staged) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(c->device));
-    const size_t bytes = c->esize() * (size_t)c->p_stride;
-    if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));
-    // stage F into the padded device layout in the covariance's element type.  F is caller-owned pageable host
-    // memory and may be released as soon as this call returns, so the copy is synchronous.
-    HIPCHK(hipMemsetAsync(c->wF, 0, bytes, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->dtype == NUSLAM_F64) {
-        HIPCHK(hipMemcpy2D(c->wF, sizeof(double) * c->ld, F, sizeof(double) * ldf, sizeof(double) * c->L, c->L,
-                           hipMemcpyHostToDevice));
-    } else {
-        std::vector<float> tmp((size_t)c->L * c->L);
-        for (int j = 0; j < c->L; ++j)
-            for (int i = 0; i < c->L; ++i) tmp[i + (size_t)j * c->L] = (float)F[i + (size_t)j * ldf];
-        HIPCHK(hipMemcpy2D(c->wF, sizeof(float) * c->ld, tmp.data(), sizeof(float) * c->L, sizeof(float) * c->L, c->L,
-                           hipMemcpyHostToDevice));
+    if (F) {
+        const size_t bytes = c->esize() * (size_t)c->p_stride;
+        if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));
+        // stage F into the padded device layout in the covariance's element type.  F is caller-owned pageable host
+        // memory and may be released as soon as this call returns, so the copy is synchronous.
+        HIPCHK(hipMemsetAsync(c->wF, 0, bytes, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->dtype == NUSLAM_F64) {
+            HIPCHK(hipMemcpy2D(c->wF, sizeof(double) * c->ld, F, sizeof(double) * ldf, sizeof(double) * c->L, c->L,
+                               hipMemcpyHostToDevice));
+        } else {
+            std::vector<float> tmp((size_t)c->L * c->L);
+            for (int j = 0; j < c->L; ++j)
+                for (int i = 0; i < c->L; ++i) tmp[i + (size_t)j * c->L] = (float)F[i + (size_t)j * ldf];
+            HIPCHK(hipMemcpy2D(c->wF, sizeof(float) * c->ld, tmp.data(), sizeof(float) * c->L, sizeof(float) * c->L, c->L,
+                               hipMemcpyHostToDevice));
+        }
+        c->f_staged = true;
     }
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
-    if (c->prof)
-        for (auto& e : ev) { e = get_event(c); if (!e) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; } }
-    // T = F P into the idle covariance buffer (every row < ld of every column is written), then P = T F^T + Qbar
-    int rc = dense_predict_launch(c->dtype, c->L, c->ld, c->wF, c->P(), c->Palt(), c->Q, c->stream, ev);
-    if (c->prof) {
-        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[0], ev[1]);
-        c->pending[NUSLAM_K_DENSE_GEMM].emplace_back(ev[2], ev[3]);
-    }
-    if (rc) { g_hip_err = "dense_predict_launch failed"; return NUSLAM_E_HIP; }
-    HIPCHK(hipGetLastError());
+    return launch_dense(c);
+}
+
+int nuslam_ekf_use_dense_predict(nuslam_ekf_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    if (enable && !h->core->f_staged) return NUSLAM_E_ARG;
+    h->core->dense_predict = enable != 0;
     return NUSLAM_OK;
 }
 

@@ -36,6 +36,7 @@ SYMBOLS = [
     ("nuslam_ekf_clone", C.c_int, [_vp, _vpp]),
     ("nuslam_ekf_predict", C.c_int, [_vp, C.c_double, C.c_double, C.c_double]),
     ("nuslam_ekf_predict_dense", C.c_int, [_vp, _dp, C.c_int]),
+    ("nuslam_ekf_use_dense_predict", C.c_int, [_vp, C.c_int]),
     ("nuslam_ekf_update", C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     ("nuslam_ekf_associate", C.c_int, [_vp, C.c_double, C.c_double, _ip]),
     ("nuslam_ekf_init_landmark", C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
@@ -299,9 +300,15 @@ class EKF:
     def predict(self, dth, dx, dy=0.0):
         _chk(lib().nuslam_ekf_predict(self._h, dth, dx, dy), "ekf_predict")
 
-    def predict_dense(self, F):
+    def predict_dense(self, F=None):
+        if F is None:
+            _chk(lib().nuslam_ekf_predict_dense(self._h, None, 0), "ekf_predict_dense")
+            return
         Fc = np.asfortranarray(F, dtype=np.float64)
         _chk(lib().nuslam_ekf_predict_dense(self._h, Fc.ctypes.data_as(_dp), Fc.shape[0]), "ekf_predict_dense")
+
+    def use_dense_predict(self, enable=True):
+        _chk(lib().nuslam_ekf_use_dense_predict(self._h, 1 if enable else 0), "ekf_use_dense_predict")
 
     def update(self, r, phi, idx):
         _chk(lib().nuslam_ekf_update(self._h, r, phi, idx), "ekf_update")

@@ -179,3 +179,88 @@ def test_cpp_host_mirror_replays_slam_loop(hip):
     P = np.array([float(x) for x in next(r for r in rows if r[0] == "P")[1:]]).reshape((o.len, o.len), order="F")
     assert np.allclose(S, o.state, atol=1e-4, rtol=0)
     assert np.linalg.norm(P - o.cov) / np.linalg.norm(o.cov) < 1e-4
+
+
+# ------------------------------------------------------------------ dense predict inside the tick
+def test_tick_with_resident_dense_jacobian(hip):
+    """use_dense_predict: predict() advances the state and propagates P with the resident dense Jacobian on the
+    matrix cores.  With F = the reference's own A = I + B for that twist it must reproduce the ordinary tick."""
+    n, m = 20, 6
+    o, lm = warm_oracle(n)
+    tr = synth.make_trace(n, 1, m, landmarks=lm)
+    s0, P0 = o.state.copy(), o.cov.copy()
+    dth, dx = tr.tw[0][0], tr.tw[0][1]
+    th1 = s0[0] + dth                                   # getA is evaluated at the advanced heading (:66-67,129)
+    r = dx / dth
+    F = np.eye(o.len)
+    F[1, 0] = -r * np.cos(th1) + r * np.cos(th1 + dth)
+    F[2, 0] = -r * np.sin(th1) + r * np.sin(th1 + dth)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    g.restore(s0, P0, n)
+    g.predict_dense(F)                                  # stages F (and applies it once)
+    g.restore(s0, P0, n)
+    g.use_dense_predict(True)
+    g.tick(tr.tw[0], tr.mx[0], tr.my[0], known_ids=tr.ids[0], want_ids=False)
+    o.tick(tw=tr.tw[0], mx=tr.mx[0], my=tr.my[0], known_ids=tr.ids[0])
+    assert np.abs(g.state - o.state).max() < 1e-12
+    assert np.abs(g.cov - o.cov).max() / np.abs(o.cov).max() < 1e-12
+
+
+# ------------------------------------------------------------------ size-independent properties at BASELINE sizes
+@pytest.mark.parametrize("n,dtype,tol", [(1000, 0, 1e-6), (5000, 1, 2e-4)])
+def test_full_size_properties(hip, n, dtype, tol):
+    """BASELINE configs[1] / [2] sizes, where a dense oracle run is out of reach: properties the EKF algebra
+    guarantees in exact arithmetic -- symmetry of P, non-negative diagonal, trace(P) never grows under a
+    correction, a correction with zero innovation leaves the state alone, restore/get round-trips.
+    Symmetry tolerance: the reference never symmetrises P and the INT_MAX cold start leaves ~1e-7 relative
+    asymmetry in fp64 (the reference's own P is 5e-7 asymmetric after step 0)."""
+    m = 16
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, 3, m, landmarks=lm)
+    bx, by, ids = synth.warmup_observations(lm)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+    g.tick(np.zeros(3), bx, by, known_ids=ids, want_ids=False)      # initialise every landmark
+    assert g.seen == n and g.status() == 0
+    P = g.cov
+    scale = np.abs(P).max()
+    assert np.isfinite(P).all() and np.diag(P).min() >= 0
+    assert np.abs(P - P.T).max() / scale < tol
+    r, b = tr.polar()
+    tr_prev = np.trace(P)
+    for t in range(tr.ticks):
+        g.predict(tr.tw[t][0], tr.tw[t][1])
+        tr_prev = np.trace(g.cov)
+        for i in range(m):
+            g.update(r[t, i], b[t, i], int(tr.ids[t, i]))
+        tr_now = np.trace(g.cov)
+        assert tr_now <= tr_prev * (1 + 1e-6)
+        tr_prev = tr_now
+    P = g.cov
+    assert np.abs(P - P.T).max() / np.abs(P).max() < tol and np.diag(P).min() >= -tol * np.abs(P).max()
+    # zero innovation: measuring exactly what the filter expects changes no state entry beyond rounding
+    s = g.state
+    j = int(tr.ids[0, 0])
+    z = hip.measurement(s, j)
+    g.update(z[0], z[1], j)
+    assert np.abs(g.state - s).max() < 1e-9
+    # snapshot / restore round trip (fp32 storage rounds P once)
+    s, P, seen = g.state, g.cov, g.seen
+    g.restore(s, P, seen)
+    assert np.array_equal(g.state, s) and np.array_equal(g.cov, P) and g.seen == seen
+
+
+def test_batch_equals_single_at_config4_size(hip):
+    n, m, T, B = 200, 16, 2, 6
+    tr = synth.make_trace(n, T, m)
+    bx, by, ids = synth.warmup_observations(tr.landmarks)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    g.tick(np.zeros(3), bx, by, known_ids=ids, want_ids=False)
+    for t in range(T):
+        g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+    bt = hip.Batch(B, n, Q, R)
+    bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], ids[None, :], bcast=True)
+    bt.run(0, 1)
+    bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+    bt.run(0, T)
+    for b in (0, B - 1):
+        assert np.array_equal(bt.state(b), g.state) and np.array_equal(bt.cov(b), g.cov)
