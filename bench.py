@@ -114,7 +114,9 @@ def main():
     # indexes out of bounds on a full map (slam_library.cpp:206-207), so the world holds n-1 landmarks there
     n_world = n if known else n - 1
     tr = synth.make_trace(n_world, W + 2 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
-    bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed)
+    # association only matches when the innovation is ~100x below sqrt(R) (threshold 0.01, slam_library.cpp:193,238),
+    # so that workload measures with 1e-4 m marker noise, in the map-initialising pass too
+    bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed, noise_sigma=None if known else 1e-4)
     Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
     if not known:
         # With the node's Q = diag(0.1) every prediction inflates the pose covariance so much that an earlier-indexed

@@ -47,6 +47,11 @@ constexpr int BM = 128, BN = 128, BK = 16;
 //   A   : (i,k) at A[i + k*ld]                         (contiguous along i)
 //   Bop : B_KMAJOR ? B[k + j*ld] : B[j + k*ld]         (first GEMM: B = P, k-major; second: B = F used as F^T)
 // 256 threads = 4 waves in a 2x2 grid, each wave owns a 64x64 sub-tile.
+//
+// Pipeline: two LDS stages; while the MFMAs of K-tile t run from stage t&1, the global loads of tile t+1 are in
+// flight into registers and are written to stage (t+1)&1 after the compute -- one barrier per K-tile.
+// Workgroup order: the linear id is remapped so that the workgroups dealt to one XCD (ids congruent mod 8) cover a
+// contiguous band of block rows and share their B strips in that XCD's L2.
 template <typename T, bool B_KMAJOR, bool ADD_Q>
 __global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict__ A, const T* __restrict__ B,
                                               T* __restrict__ C, double q00, double q10, double q20, double q01,
@@ -57,14 +62,24 @@ __global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict
     constexpr int VEC = 16 / sizeof(T);
     constexpr int NT = 64 / M::TM;            // MFMA tiles per wave edge
     constexpr int PB = B_KMAJOR ? 1 : 0;      // odd row stride -> conflict-free transposing stores
-    __shared__ T As[BK][BM];
-    __shared__ T Bs[BK][BN + PB];
+    constexpr int AV = BM / VEC;              // 16-byte vectors per k-row of the A tile
+    constexpr int NA = (BK * AV) / 256;       // vectors per thread, A tile
+    constexpr int KV = BK / VEC;              // vectors per column of a k-major B tile
+    constexpr int BV = BN / VEC;
+    constexpr int NB = B_KMAJOR ? (BN * KV) / 256 : (BK * BV) / 256;
+    __shared__ T As[2][BK][BM];
+    __shared__ T Bs[2][BK][BN + PB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int it = (wave & 1) * 64, jt = (wave >> 1) * 64;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    // XCD-aware tile order (bijective for any grid size)
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * gx + blockIdx.x;
+    const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int i0 = (wg % gx) * BM, j0 = (wg / gx) * BN;
     const int idx = M::idx(lane), kk = M::kk(lane);
 
     acc_t acc[NT][NT];
@@ -75,59 +90,69 @@ __global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict
 #pragma unroll
             for (int r = 0; r < M::NACC; ++r) acc[a][b][r] = 0;
 
-    for (int k0 = 0; k0 < L; k0 += BK) {
-        // ---- stage A tile: BK rows of k, BM contiguous i
-        constexpr int AV = BM / VEC;                 // vectors per k-row
+    V16<T> ra[NA], rb[NB];
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int s = 0; s < (BK * AV) / 256; ++s) {
+        for (int s = 0; s < NA; ++s) {
             const int v = tid + s * 256;
             const int k = v / AV, iv = (v % AV) * VEC;
-            V16<T> x;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) x.v[e] = 0;
-            if (k0 + k < L && i0 + iv < ld) x = *reinterpret_cast<const V16<T>*>(A + (size_t)(k0 + k) * ld + i0 + iv);
-            *reinterpret_cast<V16<T>*>(&As[k][iv]) = x;
+            for (int e = 0; e < VEC; ++e) ra[s].v[e] = 0;
+            if (k0 + k < L && i0 + iv < ld) ra[s] = *reinterpret_cast<const V16<T>*>(A + (size_t)(k0 + k) * ld + i0 + iv);
         }
-        // ---- stage B tile into Bs[k][j]
-        if (B_KMAJOR) {
-            constexpr int KV = BK / VEC;             // vectors per column
 #pragma unroll
-            for (int s = 0; s < (BN * KV) / 256; ++s) {
-                const int v = tid + s * 256;
+        for (int s = 0; s < NB; ++s) {
+            const int v = tid + s * 256;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) rb[s].v[e] = 0;
+            if (B_KMAJOR) {
                 const int kq = (v % KV) * VEC, j = v / KV;
-                V16<T> x;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) x.v[e] = 0;
-                if (j0 + j < L && k0 + kq < ld) x = *reinterpret_cast<const V16<T>*>(B + (size_t)(j0 + j) * ld + k0 + kq);
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) Bs[kq + e][j] = x.v[e];
-            }
-        } else {
-            constexpr int BV = BN / VEC;
-#pragma unroll
-            for (int s = 0; s < (BK * BV) / 256; ++s) {
-                const int v = tid + s * 256;
+                if (j0 + j < L && k0 + kq < ld) rb[s] = *reinterpret_cast<const V16<T>*>(B + (size_t)(j0 + j) * ld + k0 + kq);
+            } else {
                 const int k = v / BV, jv = (v % BV) * VEC;
-                V16<T> x;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) x.v[e] = 0;
-                if (k0 + k < L && j0 + jv < ld) x = *reinterpret_cast<const V16<T>*>(B + (size_t)(k0 + k) * ld + j0 + jv);
-                *reinterpret_cast<V16<T>*>(&Bs[k][jv]) = x;
+                if (k0 + k < L && j0 + jv < ld) rb[s] = *reinterpret_cast<const V16<T>*>(B + (size_t)(k0 + k) * ld + j0 + jv);
             }
         }
-        __syncthreads();
+    };
+    auto lstore = [&](int st) {
+#pragma unroll
+        for (int s = 0; s < NA; ++s) {
+            const int v = tid + s * 256;
+            *reinterpret_cast<V16<T>*>(&As[st][v / AV][(v % AV) * VEC]) = ra[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const int v = tid + s * 256;
+            if (B_KMAJOR) {
+                const int kq = (v % KV) * VEC, j = v / KV;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) Bs[st][kq + e][j] = rb[s].v[e];
+            } else {
+                *reinterpret_cast<V16<T>*>(&Bs[st][v / BV][(v % BV) * VEC]) = rb[s];
+            }
+        }
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = (L + BK - 1) / BK;
+    for (int t = 0; t < nk; ++t) {
+        const int st = t & 1;
+        if (t + 1 < nk) gload((t + 1) * BK);              // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < BK; ks += M::TK) {
             T af[NT], bf[NT];
 #pragma unroll
-            for (int a = 0; a < NT; ++a) af[a] = Bs[ks + kk][jt + a * M::TM + idx];   // MFMA A operand <- our B tile
+            for (int a = 0; a < NT; ++a) af[a] = Bs[st][ks + kk][jt + a * M::TM + idx];   // MFMA A operand <- our B tile
 #pragma unroll
-            for (int b = 0; b < NT; ++b) bf[b] = As[ks + kk][it + b * M::TM + idx];   // MFMA B operand <- our A tile
+            for (int b = 0; b < NT; ++b) bf[b] = As[st][ks + kk][it + b * M::TM + idx];   // MFMA B operand <- our A tile
 #pragma unroll
             for (int a = 0; a < NT; ++a)
 #pragma unroll
                 for (int b = 0; b < NT; ++b) acc[a][b] = M::run(af[a], bf[b], acc[a][b]);
         }
+        if (t + 1 < nk) lstore(st ^ 1);                   // stage st^1 was last read in iteration t-1 (barrier since)
         __syncthreads();
     }
 

@@ -22,12 +22,36 @@ struct View {
     const int* c_in;      // [B][C_WORDS]
     int* c_out;
     long long p_stride;   // elements between consecutive filters' covariance (ld * L)
-    int* cur_id;          // [B] id resolved by associate
+    int* cur_id;          // [B] id resolved by the stand-alone associate entry point
+    int* akey;            // [B][2] association keys: min over candidates of 4k + outcome, INT_MAX = none (two slots,
+    int aslot;            //        used alternately: the consumer of slot s re-arms slot s^1)
     int* id_log;          // [B][log_stride] resolved id per observation of the current tick (may be null)
     int log_stride;
     double Q[9];          // 3x3 column-major process noise   (slam_library.hpp:27)
     double R[4];          // 2x2 column-major sensor noise    (slam_library.hpp:28)
 };
+
+constexpr int kNoKey = 0x7fffffff;
+
+// Turn the reduced association key into associateLandmark's return value (slam_library.cpp:197-200, 206-207,
+// 238-252).  outcome code: 0 = match (d < 0.01), 1 = gray zone (0.01 < d < 60), 2 = psi singular.
+struct Assoc { int id, new_seen, new_status; };
+__device__ inline Assoc decode_association(int n, int seen, int brk, int status, int key)
+{
+    Assoc a;
+    a.id = 0; a.new_seen = seen; a.new_status = status;
+    if (brk) { a.id = 0; }                                               // marker loop already left (slam.cpp:315)
+    else if (seen == 0) { a.new_seen = 1; a.id = 1; }                    // :197-200
+    else if (seen >= n) { a.id = -1; if (status == 0) a.new_status = 2; } // :206-207 out-of-bounds write -> NUSLAM_E_BOUNDS
+    else if (key == kNoKey) { a.new_seen = seen + 1; a.id = a.new_seen; } // :251-252
+    else {
+        const int code = key & 3;
+        if (code == 0) a.id = key >> 2;
+        else if (code == 1) a.id = -1;
+        else { a.id = -1; if (status == 0) a.new_status = 3; }           // NUSLAM_E_SINGULAR
+    }
+    return a;
+}
 
 // One observation per filter: either inline (single-filter API) or from a trace resident in HBM.
 struct ObsArg {

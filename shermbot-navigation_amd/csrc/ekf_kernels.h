@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_init(View v, const double* __restrict__
     s1[(size_t)b * v.ld + t] = val;
     if (t >= 3 && t < v.L) P[(size_t)b * v.p_stride + (size_t)t * v.ld + t] = (T)2147483647.0; // INT_MAX, :30
     if (t < C_WORDS) { c0[b * C_WORDS + t] = 0; c1[b * C_WORDS + t] = 0; }
+    if (t < 2) v.akey[2 * b + t] = kNoKey;
 }
 
 // ------------------------------------------------------------------------------------------------ predict
@@ -143,44 +144,29 @@ __device__ inline int wave_min(int x)
     return x;
 }
 
-// associateLandmark, slam_library.cpp:188-253.  One workgroup per filter; candidate k is handled by thread
-// (k-1) mod 256.  The reference walks k = 1..seen and stops at the first k whose distance is < 0.01 (match)
-// or in (0.01, 60) (gray zone); that is the minimum k over a per-candidate predicate, found by a min-reduction.
+// associateLandmark, slam_library.cpp:188-253.  One lane per candidate landmark, one wave per workgroup, so the
+// candidates of one filter spread over ceil(seen/64) CUs.  The reference walks k = 1..seen and stops at the first k
+// whose distance is < 0.01 (match) or in (0.01, 60) (gray zone): that is the minimum k over a per-candidate
+// predicate -> wave min, then one atomicMin per wave on the filter's key slot.  The key is decoded by the consumer
+// (k_update in a tick, k_associate_finish for the stand-alone entry point).
 template <typename T>
-__global__ __launch_bounds__(256) void k_associate(View v, ObsArg o, const T* __restrict__ P)
+__global__ __launch_bounds__(64) void k_associate(View v, ObsArg o, const T* __restrict__ P)
 {
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
     const int* ci = v.c_in + b * C_WORDS;
-    int* co = v.c_out + b * C_WORDS;
     const int seen = ci[C_SEEN];
-    const int brk = ci[C_BRK];
+    if (ci[C_BRK] || seen == 0 || seen >= v.n) return;        // decided without looking at any candidate
+    if ((int)blockIdx.x * 64 >= seen) return;
+    const int k = blockIdx.x * 64 + threadIdx.x + 1;
     const double* s = v.s_in + (size_t)b * v.ld;
-    __shared__ int s_min[4];
-
-    int done = 0, id = 0, new_seen = seen, new_status = ci[C_STATUS];
-    if (brk) { done = 1; id = 0; }                                       // loop already left (slam.cpp:315)
-    else if (seen == 0) { done = 1; new_seen = 1; id = 1; }              // :197-200
-    else if (seen >= v.n) {                                              // :206-207 out-of-bounds write
-        done = 1; id = -1;
-        if (new_status == 0) new_status = kStatusBounds;
-    }
-    if (done) {
-        if (tid == 0) {
-            v.cur_id[b] = id;
-            co[C_SEEN] = new_seen; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = brk; co[C_STATUS] = new_status;
-        }
-        return;
-    }
-
-    double r, phi;
-    fetch_obs(o, b, r, phi);
-    const double th = s[0], x = s[1], y = s[2];
-    const T* Pb = P + (size_t)b * v.p_stride;
-    const double min_threshold = 0.01;   // :193
-    const double max_threshold = 60;     // :194
-    int key = 0x7fffffff;
-    for (int k = tid + 1; k <= seen; k += 256) {
+    int key = kNoKey;
+    if (k <= seen) {
+        double r, phi;
+        fetch_obs(o, b, r, phi);
+        const double th = s[0], x = s[1], y = s[2];
+        const T* Pb = P + (size_t)b * v.p_stride;
+        const double min_threshold = 0.01;   // :193
+        const double max_threshold = 60;     // :194
         const int c = 3 + 2 * (k - 1);
         const double lx = s[c], ly = s[c + 1];
         double Hc[10], psi[4], psi_inv[4], zr, zb;
@@ -199,23 +185,23 @@ __global__ __launch_bounds__(256) void k_associate(View v, ObsArg o, const T* __
             if (d < min_threshold) code = 0;                                   // :238
             else if ((d > min_threshold) && (d < max_threshold)) code = 1;     // :243
         }
-        if (code >= 0) { const int kk = k * 4 + code; key = kk < key ? kk : key; }
+        if (code >= 0) key = k * 4 + code;
     }
     key = wave_min(key);
-    if ((tid & 63) == 0) s_min[tid >> 6] = key;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; ++w) key = s_min[w] < key ? s_min[w] : key;
-        if (key == 0x7fffffff) { new_seen = seen + 1; id = new_seen; }         // :251-252
-        else {
-            const int code = key & 3;
-            if (code == 0) id = key >> 2;
-            else if (code == 1) id = -1;
-            else { id = -1; if (new_status == 0) new_status = kStatusSingular; }
-        }
-        v.cur_id[b] = id;
-        co[C_SEEN] = new_seen; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = brk; co[C_STATUS] = new_status;
-    }
+    if (threadIdx.x == 0 && key != kNoKey) atomicMin(v.akey + 2 * b + v.aslot, key);
+}
+
+// Stand-alone associateLandmark(): decode the key, publish the id, count a new landmark, re-arm the other slot.
+__global__ void k_associate_finish(View v)
+{
+    const int b = blockIdx.x;
+    const int* ci = v.c_in + b * C_WORDS;
+    int* co = v.c_out + b * C_WORDS;
+    const Assoc a = decode_association(v.n, ci[C_SEEN], ci[C_BRK], ci[C_STATUS], v.akey[2 * b + v.aslot]);
+    v.cur_id[b] = a.id;
+    co[C_SEEN] = a.new_seen; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = ci[C_BRK]; co[C_STATUS] = a.new_status;
+    v.akey[2 * b + v.aslot] = kNoKey;         // consumed
+    v.akey[2 * b + (v.aslot ^ 1)] = kNoKey;
 }
 
 // ------------------------------------------------------------------------------------------------ init landmark

@@ -114,7 +114,14 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     // whenever the decision below keeps the update.
     const int* ci = v.c_in + b * C_WORDS;
     const int seen = ci[C_SEEN], cached = ci[C_SEEN_CACHED], brk = ci[C_BRK], status0 = ci[C_STATUS];
-    const int id_raw = (MODE == MODE_DA) ? v.cur_id[b] : (INLINE_ID ? o.id0 : o.ids[b * o.stride + o.off]);
+    int seen_now = seen, status_now = status0;
+    int id_raw;
+    if (MODE == MODE_DA) {                                // associateLandmark's verdict, from the reduced key
+        const Assoc a = decode_association(v.n, seen, brk, status0, v.akey[2 * b + v.aslot]);
+        id_raw = a.id; seen_now = a.new_seen; status_now = a.new_status;
+    } else {
+        id_raw = INLINE_ID ? o.id0 : o.ids[b * o.stride + o.off];
+    }
     const int cg = (id_raw >= 1 && id_raw <= v.n) ? 3 + 2 * (id_raw - 1) : 3;
     const double* s = v.s_in + (size_t)b * ld;
     const T* Pb = Pin + (size_t)b * v.p_stride;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
         pc[q] = *reinterpret_cast<const vec_t*>(Pb + (size_t)(q < 3 ? q : cg + (q - 3)) * ld + rowc);
 
     // (3) decision (every wave: a few scalar compares) + the shared quantities (wave 0, then LDS)
-    const Decision d = resolve(v.n, id_raw, seen, cached, brk, status0, mode, total_landmarks);
+    const Decision d = resolve(v.n, id_raw, seen_now, cached, brk, status_now, mode, total_landmarks);
     double* so = v.s_out + (size_t)b * ld;
     const int c = d.c;                                    // == cg unless skipped
     const int set[5] = { 0, 1, 2, c, c + 1 };
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
         int* co = v.c_out + b * C_WORDS;
         co[C_SEEN] = d.new_seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = d.new_brk; co[C_STATUS] = new_status;
         if (v.id_log && o.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot] = d.id;
+        if (MODE == MODE_DA) v.akey[2 * b + (v.aslot ^ 1)] = kNoKey;     // re-arm the slot the next association uses
     }
     T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
 

@@ -50,6 +50,8 @@ struct nuslam_batch {
     int pidx = 0;
     long long p_stride = 0;
     int* cur_id = nullptr;
+    int* akey = nullptr;       // [B][2] association key slots
+    int aslot = 0;
     double* tr = nullptr;      // per-filter trace scratch
     double* stats = nullptr;   // 2L + 2
     double Q[9], R[4];
@@ -83,7 +85,7 @@ struct nuslam_batch {
         v.s_in = state[sidx]; v.s_out = state[sidx ^ 1];
         v.c_in = ctrl[cidx]; v.c_out = ctrl[cidx ^ 1];
         v.p_stride = p_stride;
-        v.cur_id = cur_id; v.id_log = id_log; v.log_stride = log_stride;
+        v.cur_id = cur_id; v.akey = akey; v.aslot = aslot; v.id_log = id_log; v.log_stride = log_stride;
         memcpy(v.Q, Q, sizeof(Q));
         memcpy(v.R, R, sizeof(R));
         return v;
@@ -180,14 +182,23 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
     return NUSLAM_OK;
 }
 
+// Launches the candidate scan only; the key is consumed by the next do_update(MODE_DA) or by associate_finish().
 int do_associate(nuslam_batch* h, const ObsArg& o)
 {
     View v = h->view();
-    dim3 grid(h->B), block(256);
+    dim3 grid((h->n + 63) / 64 > 0 ? (h->n + 63) / 64 : 1, h->B), block(64);
     int rc = NUSLAM_OK;
     DISPATCH_T(h, rc = launch(h, NUSLAM_K_ASSOCIATE, k_associate<T>, grid, block, v, o, (const T*)h->P()));
+    return rc;
+}
+
+int associate_finish(nuslam_batch* h)
+{
+    View v = h->view();
+    int rc = launch(h, -1, k_associate_finish, dim3(h->B), dim3(1), v);
     if (rc) return rc;
     h->cidx ^= 1;
+    h->aslot ^= 1;
     return NUSLAM_OK;
 }
 
@@ -210,6 +221,7 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     h->sidx ^= 1;
     h->cidx ^= 1;
     h->pidx ^= 1;
+    if (mode == MODE_DA) h->aslot ^= 1;
     return NUSLAM_OK;
 }
 
@@ -240,7 +252,7 @@ void free_batch(nuslam_batch* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->tr,
+    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->tr,
                      h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
@@ -277,6 +289,7 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
         HIPCHK(hipMalloc(&h->Pbuf[0], h->esize() * (size_t)B * h->p_stride));
         HIPCHK(hipMalloc(&h->Pbuf[1], h->esize() * (size_t)B * h->p_stride));
         HIPCHK(hipMalloc(&h->cur_id, sizeof(int) * B));
+        HIPCHK(hipMalloc(&h->akey, sizeof(int) * 2 * B));
         HIPCHK(hipMalloc(&h->tr, sizeof(double) * B));
         HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 2)));
         HIPCHK(hipMemsetAsync(h->cur_id, 0, sizeof(int) * B, h->stream));
@@ -316,7 +329,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     if (d_map) (void)hipFree(d_map);
     if (rc) return rc;
     HIPCHK(e);
-    h->sidx = 0; h->cidx = 0; h->pidx = 0;
+    h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
     return NUSLAM_OK;
 }
 
@@ -694,6 +707,9 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
         HIPCHK(hipMemcpy(d->ctrl[0], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy(d->ctrl[1], s->ctrl[s->cidx], sizeof(int) * C_WORDS, hipMemcpyDeviceToDevice));
         HIPCHK(hipMemcpy(d->P(), s->P(), s->esize() * (size_t)s->p_stride, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemset(d->akey, 0x7f, sizeof(int) * 2));      // overwritten just below with the exact sentinel
+        const int nokey[2] = { 0x7fffffff, 0x7fffffff };
+        HIPCHK(hipMemcpy(d->akey, nokey, sizeof(nokey), hipMemcpyHostToDevice));
         return NUSLAM_OK;
     }();
     if (rc) { free_batch(d); return rc; }
@@ -743,6 +759,7 @@ int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_
     nuslam_batch* c = h->core;
     HIPCHK(hipSetDevice(c->device));
     int rc = do_associate(c, inline_obs(range, bearing, 0, 0));
+    if (!rc) rc = associate_finish(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(id_out, c->cur_id, sizeof(int), hipMemcpyDeviceToHost));

