@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--m", type=int, default=16, help="corrections per tick")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--deferred", action="store_true",
+                    help="opt-in deferred application: a tick's corrections are kept as rank-2 factors and applied to P "
+                         "once per tick (csrc/ekf_deferred.h); results agree with the default to rounding, not bitwise")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="attach the per-dispatch HIP events inside the timed region itself (costs ~25%% throughput: "
                          "every dispatch then carries a completion signal); default: a second pass of K identical steps "
@@ -151,6 +154,8 @@ def main():
         warm_state = None
     ids = tr.ids if known else None
     bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
+    if args.deferred:
+        bt.set_deferred(True)
 
     def barrier():
         if world > 1:
@@ -180,6 +185,8 @@ def main():
     pred_ms, pred_n = bt.profile_read(nh.K_PREDICT)
     asso_ms, asso_n = bt.profile_read(nh.K_ASSOCIATE)
     gemm_ms, gemm_n = bt.profile_read(nh.K_DENSE_GEMM)
+    dupd_ms, dupd_n = bt.profile_read(nh.K_UPDATE_DEFERRED)
+    flush_ms, flush_n = bt.profile_read(nh.K_FLUSH)
     bt.profile(False)
     bad, st = bt.status()
     if st != 0:
@@ -239,6 +246,19 @@ def main():
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
+    if args.deferred and flush_n:
+        # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved);
+        # "effective" = the eager formula (2*L^2*w per correction) over the time actually spent per correction
+        per_launch_bytes = 2.0 * L * L * w * B
+        avg_s = 1e-3 * flush_ms / flush_n
+        ach = per_launch_bytes / avg_s / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_flush", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": flush_n,
+                           "algorithmic_bytes_per_launch": per_launch_bytes,
+                           "effective_GBps_eager_formula": per_launch_bytes * out["value"] / (world * B) / 1e9}
+        out["kernel_us"] = {"update_deferred": 1e3 * dupd_ms / max(dupd_n, 1), "flush": 1e3 * flush_ms / flush_n,
+                            "predict": 1e3 * pred_ms / max(pred_n, 1)}
+        out["config"]["deferred"] = True
     if gemm_n:
         flop = 2.0 * L ** 3                                    # one of the two products of F P F^T
         avg_s = 1e-3 * gemm_ms / gemm_n

@@ -131,13 +131,23 @@ int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len);
 /* a one-filter view for the single-filter API above is the batch of size 1: */
 int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do not destroy */
 
+/* Deferred application (opt-in; known association only).  The corrections of a tick are kept as rank-2 factors,
+ * P_j = P_0 - sum U_i V_i with U_i = K_i and V_i = H_i P_{i-1} -- the reference's update (slam_library.cpp:270-279)
+ * re-associated -- and the covariance is rewritten once per tick (before the next predict, or when a getter,
+ * association or 16 pending corrections force it): 2 len^2 w bytes per TICK instead of per correction.
+ * Results agree with the default eager path to rounding, not bit for bit. */
+int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
+int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
+
 /* ------------------------------------------------------------------ measurement hooks */
 typedef enum {
     NUSLAM_K_PREDICT = 0,
     NUSLAM_K_ASSOCIATE = 1,
     NUSLAM_K_UPDATE = 2,       /* the streaming correction sweep: the HBM-bound kernel */
     NUSLAM_K_DENSE_GEMM = 3,   /* the two MFMA products of nuslam_ekf_predict_dense */
-    NUSLAM_K_COUNT = 4
+    NUSLAM_K_UPDATE_DEFERRED = 4, /* one correction in factor form, O(len) (deferred mode) */
+    NUSLAM_K_FLUSH = 5,        /* the rank-2J pass that applies a tick's pending corrections (deferred mode) */
+    NUSLAM_K_COUNT = 6
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

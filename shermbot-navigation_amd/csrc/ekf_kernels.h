@@ -266,3 +266,4 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 } // namespace nuslam
 
 #include "ekf_update.h"
+#include "ekf_deferred.h"

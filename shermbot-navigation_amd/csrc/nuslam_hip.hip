@@ -65,6 +65,10 @@ struct nuslam_batch {
     // dense predict: staged Jacobian (element type = dtype); the product T = F P goes to the idle P buffer
     void* wF = nullptr;
     bool f_staged = false;
+    // deferred application: pending rank-2 factors U_i = K_i, V_i = H_i P_{i-1}
+    bool deferred = false;
+    double* dU = nullptr; double* dV = nullptr;
+    int J = 0;
     bool dense_predict = false;   // do_predict: state-only kernel + the two MFMA products with the staged Jacobian
     // profiling
     bool prof = false;
@@ -149,6 +153,22 @@ int drain_profile(nuslam_batch* h)
         else { typedef double T; CALL; }                      \
     } while (0)
 
+// apply the pending factors: P <- P - sum U_i V_i
+int flush_pending(nuslam_batch* h)
+{
+    if (h->J == 0) return NUSLAM_OK;
+    View v = h->view();
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_FLUSH, k_flush<T>, grid, block, v, h->J, (T*)h->P(), (const double*)h->dU,
+                               (const double*)h->dV)));
+    if (rc) return rc;
+    h->J = 0;
+    return NUSLAM_OK;
+}
+
 int launch_dense(nuslam_batch* c)
 {
     hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -167,6 +187,8 @@ int launch_dense(nuslam_batch* c)
 
 int do_predict(nuslam_batch* h, const TwistArg& tw)
 {
+    int frc = flush_pending(h);
+    if (frc) return frc;
     View v = h->view();
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
@@ -185,6 +207,8 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
 // Launches the candidate scan only; the key is consumed by the next do_update(MODE_DA) or by associate_finish().
 int do_associate(nuslam_batch* h, const ObsArg& o)
 {
+    int frc = flush_pending(h);
+    if (frc) return frc;
     View v = h->view();
     dim3 grid((h->n + 63) / 64 > 0 ? (h->n + 63) / 64 : 1, h->B), block(64);
     int rc = NUSLAM_OK;
@@ -204,6 +228,23 @@ int associate_finish(nuslam_batch* h)
 
 int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
 {
+    if (h->deferred && mode != MODE_DA) {
+        if (h->J == kMaxPending) { int frc = flush_pending(h); if (frc) return frc; }
+        View vd = h->view();
+        dim3 gridd((h->ld + 255) / 256, 1, h->B), blockd(256);
+        int rcd = NUSLAM_OK;
+        if (o.ids == nullptr)
+            DISPATCH_T(h, rcd = (launch(h, NUSLAM_K_UPDATE_DEFERRED, k_update_deferred<T, true>, gridd, blockd, vd, o, mode,
+                                        total, h->J, (const T*)h->P(), h->dU, h->dV)));
+        else
+            DISPATCH_T(h, rcd = (launch(h, NUSLAM_K_UPDATE_DEFERRED, k_update_deferred<T, false>, gridd, blockd, vd, o, mode,
+                                        total, h->J, (const T*)h->P(), h->dU, h->dV)));
+        if (rcd) return rcd;
+        h->J += 1;
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+        return NUSLAM_OK;
+    }
     View v = h->view();
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
@@ -252,7 +293,7 @@ void free_batch(nuslam_batch* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->tr,
+    void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
                      h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
@@ -364,6 +405,7 @@ int get_cov(nuslam_batch* h, int b, double* out, int ld)
 {
     if (!h || !out || b < 0 || b >= h->B || ld < h->L) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int frc = flush_pending(h); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     const char* src = (const char*)h->P() + h->esize() * (size_t)b * h->p_stride;
     if (h->dtype == NUSLAM_F64) {
@@ -392,6 +434,7 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
 {
     if (!h || !state || !cov || b < 0 || b >= h->B || ld < h->L || seen < 0 || seen > h->n) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int frc = flush_pending(h); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> s(h->ld, 0.0);
     memcpy(s.data(), state, sizeof(double) * h->L);
@@ -611,6 +654,7 @@ int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len)
 {
     if (!h || !out || out_len < 2 * h->L + 2) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int frc = flush_pending(h); if (frc) return frc; }
     View v = h->view();
     int rc = NUSLAM_OK;
     DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P(), h->tr));
@@ -622,6 +666,25 @@ int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len)
     HIPCHK(hipMemcpy(out, h->stats, sizeof(double) * (2 * h->L + 2), hipMemcpyDeviceToHost));
     return NUSLAM_OK;
 }
+
+int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    int rc = flush_pending(h);
+    if (rc) return rc;
+    if (enable && !h->dU) {
+        const size_t bytes = sizeof(double) * (size_t)h->B * 2 * kMaxPending * h->ld;
+        HIPCHK(hipMalloc(&h->dU, bytes));
+        HIPCHK(hipMalloc(&h->dV, bytes));
+        HIPCHK(hipMemsetAsync(h->dU, 0, bytes, h->stream));
+        HIPCHK(hipMemsetAsync(h->dV, 0, bytes, h->stream));
+    }
+    h->deferred = enable != 0;
+    return NUSLAM_OK;
+}
+
+int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable) { return h ? nuslam_batch_set_deferred(h->core, enable) : NUSLAM_E_ARG; }
 
 int nuslam_batch_profile(nuslam_batch_t* h, int enable)
 {
@@ -694,6 +757,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
 {
     if (!src || !out) return NUSLAM_E_ARG;
     nuslam_batch* s = src->core;
+    { int frc = flush_pending(s); if (frc) return frc; }
     nuslam_batch* d = nullptr;
     int rc = alloc_batch(1, s->n, s->dtype, s->device, &d);
     if (rc) return rc;
@@ -836,6 +900,7 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
     nuslam_batch* c = h->core;
     if (!F && !c->f_staged) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(c->device));
+    { int frc = flush_pending(c); if (frc) return frc; }
     if (F) {
         const size_t bytes = c->esize() * (size_t)c->p_stride;
         if (!c->wF) HIPCHK(hipMalloc(&c->wF, bytes));

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libnuslam_hip.so")
 
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
 F64, F32 = 0, 1
-K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM = range(4)
+K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH = range(6)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -61,6 +61,8 @@ SYMBOLS = [
     ("nuslam_batch_status", C.c_int, [_vp, C.c_int, _ip, _ip]),
     ("nuslam_batch_stats", C.c_int, [_vp, _dp, C.c_int]),
     ("nuslam_ekf_as_batch", C.c_int, [_vp, _vpp]),
+    ("nuslam_batch_set_deferred", C.c_int, [_vp, C.c_int]),
+    ("nuslam_ekf_set_deferred", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
     ("nuslam_batch_timer_start", C.c_int, [_vp]),
@@ -238,6 +240,9 @@ class Batch:
         _chk(lib().nuslam_batch_stats(self._h, _p(out), out.size), "batch_stats")
         return out
 
+    def set_deferred(self, enable=True):
+        _chk(lib().nuslam_batch_set_deferred(self._h, 1 if enable else 0), "batch_set_deferred")
+
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")
 
@@ -306,6 +311,9 @@ class EKF:
             return
         Fc = np.asfortranarray(F, dtype=np.float64)
         _chk(lib().nuslam_ekf_predict_dense(self._h, Fc.ctypes.data_as(_dp), Fc.shape[0]), "ekf_predict_dense")
+
+    def set_deferred(self, enable=True):
+        _chk(lib().nuslam_ekf_set_deferred(self._h, 1 if enable else 0), "ekf_set_deferred")
 
     def use_dense_predict(self, enable=True):
         _chk(lib().nuslam_ekf_use_dense_predict(self._h, 1 if enable else 0), "ekf_use_dense_predict")
