@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--deferred", action="store_true",
                     help="opt-in deferred application: a tick's corrections are kept as rank-2 factors and applied to P "
                          "once per tick (csrc/ekf_deferred.h); results agree with the default to rounding, not bitwise")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the batch reduction (nccl = RCCL over xGMI; gloo only to rehearse "
+                         "the multi-rank path on one GPU)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="attach the per-dispatch HIP events inside the timed region itself (costs ~25%% throughput: "
                          "every dispatch then carries a completion signal); default: a second pass of K identical steps "
@@ -87,9 +90,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    ndev = torch.cuda.device_count()
+    dev = (local_rank % max(ndev, 1)) if world > 1 else 0
+    coll_dev = "cuda" if args.backend == "nccl" else None
 
     import nuslam_hip as nh
     from nuslam_hip import synth
@@ -116,7 +124,7 @@ def main():
     # data association needs one free slot: associateLandmark writes a hypothetical landmark at index seen+1 and
     # indexes out of bounds on a full map (slam_library.cpp:206-207), so the world holds n-1 landmarks there
     n_world = n if known else n - 1
-    tr = synth.make_trace(n_world, W + 2 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
+    tr = synth.make_trace(n_world, W + 3 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
     # association only matches when the innovation is ~100x below sqrt(R) (threshold 0.01, slam_library.cpp:193,238),
     # so that workload measures with 1e-4 m marker noise, in the map-initialising pass too
     bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed, noise_sigma=None if known else 1e-4)
@@ -188,15 +196,29 @@ def main():
     dupd_ms, dupd_n = bt.profile_read(nh.K_UPDATE_DEFERRED)
     flush_ms, flush_n = bt.profile_read(nh.K_FLUSH)
     bt.profile(False)
+    deferred_extra = None
+    if args.workload == "ekf1000" and not args.deferred and not in_region:
+        # the same K steps once more with the opt-in deferred application (reported beside the headline, never as it)
+        bt.set_deferred(True)
+        bt.run(W + 2 * K, W + 2 * K + 2)
+        barrier()
+        td = time.perf_counter()
+        bt.run(W + 2 * K + 2, W + 3 * K)
+        bt.sync()
+        td = time.perf_counter() - td
+        bt.set_deferred(False)
+        deferred_extra = {"value": float(world) * B * m * (K - 2) / td, "unit": "updates/s", "ms_per_step": 1e3 * td / (K - 2),
+                          "note": "opt-in mode (nuslam_ekf_set_deferred): a tick's corrections kept as rank-2 factors, P rewritten "
+                                  "once per tick; agrees with the default path to rounding (tests/test_gpu_deferred.py), not bitwise"}
     bad, st = bt.status()
     if st != 0:
         raise RuntimeError("device status %d on filter %d" % (st, bad))
 
     from nuslam_hip import dist as nd
     if world > 1:
-        dt = nd.max_over_ranks(dt, device="cuda")
+        dt = nd.max_over_ranks(dt, device=coll_dev)
         # the batch reduction over xGMI (RCCL): Monte-Carlo statistics of all trials, gathered and summed in rank order
-        total, _ = nd.reduce_stats(bt.stats(), device="cuda")
+        total, _ = nd.reduce_stats(bt.stats(), device=coll_dev)
         n_filters_total = int(total[-1])
     else:
         n_filters_total = B
@@ -268,8 +290,10 @@ def main():
                            "peak": peak, "unit": "TFLOP/s", "frac": flop / avg_s / 1e12 / peak, "traffic": None,
                            "avg_launch_us": 1e6 * avg_s, "launches": gemm_n, "algorithmic_flop_per_launch": flop}
         out["kernel_us"]["dense_gemm"] = 1e6 * avg_s
+    if deferred_extra is not None:
+        out["deferred_mode"] = deferred_extra
     if warm_state is not None and args.cpu_seconds > 0 and args.workload == "ekf1000":
-        cb, _ = cpu_baseline(n, m, synth.make_trace(n, W + 2 * K, m, seed=12345), args.cpu_seconds, warm_state)
+        cb, _ = cpu_baseline(n, m, synth.make_trace(n, W + 3 * K, m, seed=12345), args.cpu_seconds, warm_state)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
     print(json.dumps(out))

@@ -162,9 +162,10 @@ int flush_pending(nuslam_batch* h)
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_FLUSH, k_flush<T>, grid, block, v, h->J, (T*)h->P(), (const double*)h->dU,
-                               (const double*)h->dV)));
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_FLUSH, k_flush<T>, grid, block, v, h->J, (const T*)h->P(), (T*)h->Palt(),
+                               (const double*)h->dU, (const double*)h->dV)));
     if (rc) return rc;
+    h->pidx ^= 1;
     h->J = 0;
     return NUSLAM_OK;
 }
