@@ -143,11 +143,13 @@ def main():
         ekf.sync()
         warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None
         if args.workload == "ekf5000":
-            # the reference's own A = I + B for the first twist, handed over as a DENSE Jacobian and kept resident
+            # a DENSE Jacobian kept resident in HBM: the reference's A = I + B for the first twist plus a small dense
+            # random perturbation -- every operand non-zero, because MFMA loops on mostly-zero operands hold a higher
+            # clock and would flatter the number (cdna_hip_programming.md section 5.4 rule 25)
             dth, dx = tr.tw[0][0], tr.tw[0][1]
-            F = np.eye(L)
-            F[1, 0] = -(dx / dth) * np.cos(dth) + (dx / dth) * np.cos(2 * dth)
-            F[2, 0] = -(dx / dth) * np.sin(dth) + (dx / dth) * np.sin(2 * dth)
+            F = np.eye(L) + (1e-3 / np.sqrt(L)) * np.random.default_rng(seed).standard_normal((L, L))
+            F[1, 0] += -(dx / dth) * np.cos(dth) + (dx / dth) * np.cos(2 * dth)
+            F[2, 0] += -(dx / dth) * np.sin(dth) + (dx / dth) * np.sin(2 * dth)
             s0, P0, sn = ekf.state, ekf.cov, ekf.seen
             ekf.predict_dense(F)
             ekf.restore(s0, P0, sn)
