@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libnuslam_hip.so")
+LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_hip.so")   # override: A/B experiments only
 
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
 F64, F32 = 0, 1
