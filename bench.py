@@ -199,7 +199,7 @@ def main():
     flush_ms, flush_n = bt.profile_read(nh.K_FLUSH)
     bt.profile(False)
     deferred_extra = None
-    if args.workload == "ekf1000" and not args.deferred and not in_region:
+    if args.workload == "ekf1000" and not args.deferred and not in_region and K >= 4:
         # the same K steps once more with the opt-in deferred application (reported beside the headline, never as it)
         bt.set_deferred(True)
         bt.run(W + 2 * K, W + 2 * K + 2)

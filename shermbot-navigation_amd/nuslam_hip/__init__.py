@@ -333,9 +333,11 @@ class EKF:
         mx = np.ascontiguousarray(mx, dtype=np.float64)
         my = np.ascontiguousarray(my, dtype=np.float64)
         m = mx.size
+        assert my.size == m, "marker x / y arrays differ in length"
         kid = None
         if known_ids is not None:
             kid = np.ascontiguousarray(known_ids, dtype=np.int32)
+            assert kid.size == m, "known_ids must have one id per marker"
         ids_out = np.zeros(max(m, 1), dtype=np.int32)
         _chk(lib().nuslam_ekf_tick(self._h, tw[0], tw[1], tw[2] if len(tw) > 2 else 0.0, m, _p(mx), _p(my),
                                    kid.ctypes.data_as(_ip) if kid is not None else None,

@@ -124,3 +124,18 @@ def test_deferred_full_size(hip):
     es, ep = entry_rel_err(out[1][0], out[0][0]), entry_rel_err(out[1][1], out[0][1])
     print("deferred N=1000 vs eager: state %.1e cov %.1e" % (es, ep))
     assert es < 1e-8 and ep < 1e-6
+
+
+def test_deferred_with_data_association_falls_back_to_flush(hip):
+    """Deferred mode covers known association only: an associateLandmark forces a flush first and that marker's
+    correction takes the eager kernel, so a data-association trace gives the eager result."""
+    n, T, m = 12, 10, 4
+    tr = synth.make_trace(n, T, m, noise_sigma=1e-3)
+    ge = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    gd = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    gd.set_deferred(True)
+    for t in range(T):
+        ie = ge.tick(tr.tw[t], tr.mx[t], tr.my[t])
+        idd = gd.tick(tr.tw[t], tr.mx[t], tr.my[t])
+        assert np.array_equal(ie, idd)
+    assert np.array_equal(gd.state, ge.state) and np.array_equal(gd.cov, ge.cov) and gd.seen == ge.seen
