@@ -59,24 +59,55 @@ def parse():
 
 
 def cpu_baseline(n, m, tr, budget_s, warm_state):
-    """The reference CPU path as restated by oracle/ (dense algebra: 4L^3 per predict, 2L^3 per update), all
-    host cores, on the first ticks of the same trace, from the same post-initialisation snapshot."""
+    """The reference CPU path (dense algebra: two L^3 GEMMs per predict, one per update -- slam_library.cpp:104,279) on
+    this host's usable cores, on the first ticks of the same trace from the same post-initialisation snapshot.  Two
+    restatements are timed and the FASTER one is reported as the baseline:
+      oracle-c    oracle/nuslam_oracle.c dense mode, OpenMP-blocked loops
+      numpy-blas  tests/_np_ekf.py, the same chain through numpy's BLAS dgemm (OpenBLAS) -- what Armadillo itself
+                  would dispatch to."""
     import _oracle as O
+    import _np_ekf
     from nuslam_hip import synth
     cores = O.usable_cpus()
+    cands = {}
+
     O.set_threads(cores)
     o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT, O.ORC_DENSE)
     o.restore(*warm_state)
-    done = 0
-    t0 = time.perf_counter()
-    while done < tr.ticks and (done == 0 or time.perf_counter() - t0 < budget_s):
+    done, t0 = 0, time.perf_counter()
+    while done < tr.ticks and (done == 0 or time.perf_counter() - t0 < budget_s / 2):
         o.tick(tw=tr.tw[done], mx=tr.mx[done], my=tr.my[done], known_ids=tr.ids[done])
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": done * m / dt, "unit": "updates/s", "cores": O.lib().orc_get_threads(), "kind": "port",
-            "sample": "%d tick(s) (1 predict + %d updates each) of the same N=%d trace from the same "
-                      "post-initialisation snapshot, oracle dense mode (reference algebra: two L^3 GEMMs per predict, "
-                      "one per update), %.1f s" % (done, m, n, dt),
+    cands["oracle-c"] = (done * m / dt, done, dt)
+    O.set_threads(1)
+
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
+    e = _np_ekf.NpEKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT)
+    e.s[:] = warm_state[0]
+    e.P[:, :] = warm_state[1]
+    r, b = tr.polar()
+    done, t0 = 0, time.perf_counter()
+    while done < tr.ticks and (done == 0 or time.perf_counter() - t0 < budget_s / 2):
+        e.predict(tr.tw[done][0], tr.tw[done][1])
+        for i in range(m):
+            e.update([r[done, i], b[done, i]], int(tr.ids[done, i]))
+        done += 1
+    dt = time.perf_counter() - t0
+    cands["numpy-blas"] = (done * m / dt, done, dt)
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+
+    best = max(cands, key=lambda k: cands[k][0])
+    v, done, dt = cands[best]
+    return {"value": v, "unit": "updates/s", "cores": cores, "kind": "port", "impl": best,
+            "sample": "%d tick(s) (1 predict + %d updates each) of the same N=%d trace from the same post-initialisation "
+                      "snapshot, reference algebra (two L^3 GEMMs per predict, one per update), %.1f s; faster of "
+                      "{oracle-c: %.2f, numpy-blas: %.2f} updates/s" % (done, m, n, dt, cands["oracle-c"][0], cands["numpy-blas"][0]),
             "ms_per_step": 1e3 * dt / done}, o
 
 
