@@ -139,6 +139,16 @@ int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do 
 int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
 
+/* ------------------------------------------------------------------ landmark extraction */
+/* circle_fit::circleFit (nuslam/src/circle_fit_library.cpp:15-134) and circle_fit::classifyCluster (:208-250) for a
+ * batch of lidar clusters, one wave per cluster.  Cluster c owns points [offsets[c], offsets[c+1]) of xs / ys (host
+ * memory).  Per cluster: centre, radius (the marker's scale.x is 2 * radius, :124), status 0 ok / 1 fewer than four
+ * points (the reference returns marker.id = -1, :73-77) / 2 singular 4x4 system; optionally classifyCluster's verdict
+ * and the standard deviation of the inscribed angles in degrees.  kernel_ms (may be NULL) receives the device time. */
+int nuslam_circle_fit_batch(int n_clusters, const int* offsets, const double* xs, const double* ys, double* centre_x,
+                            double* centre_y, double* radius, int* status, int* is_circle, double* angle_std_dev,
+                            int device, double* kernel_ms);
+
 /* ------------------------------------------------------------------ measurement hooks */
 typedef enum {
     NUSLAM_K_PREDICT = 0,

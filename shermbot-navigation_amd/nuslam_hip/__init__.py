@@ -63,6 +63,7 @@ SYMBOLS = [
     ("nuslam_ekf_as_batch", C.c_int, [_vp, _vpp]),
     ("nuslam_batch_set_deferred", C.c_int, [_vp, C.c_int]),
     ("nuslam_ekf_set_deferred", C.c_int, [_vp, C.c_int]),
+    ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
     ("nuslam_batch_timer_start", C.c_int, [_vp]),
@@ -143,6 +144,26 @@ def jacobian(state, j):
     H = np.zeros((2, s.size), order="F")
     _chk(lib().nuslam_jacobian(_p(s), s.size, j, H.ctypes.data_as(_dp)), "jacobian")
     return H
+
+
+def circle_fit_batch(clusters, device=0):
+    """clusters: list of (xs, ys).  Returns dict of arrays: cx, cy, radius, status, is_circle, angle_std, kernel_ms."""
+    n = len(clusters)
+    sizes = [len(c[0]) for c in clusters]
+    off = np.zeros(n + 1, dtype=np.int32)
+    off[1:] = np.cumsum(sizes)
+    xs = np.ascontiguousarray(np.concatenate([np.asarray(c[0], dtype=np.float64) for c in clusters]) if n else np.zeros(0))
+    ys = np.ascontiguousarray(np.concatenate([np.asarray(c[1], dtype=np.float64) for c in clusters]) if n else np.zeros(0))
+    cx, cy, rad, sd = (np.zeros(max(n, 1)) for _ in range(4))
+    st = np.zeros(max(n, 1), dtype=np.int32)
+    circ = np.zeros(max(n, 1), dtype=np.int32)
+    ms = C.c_double()
+    _chk(lib().nuslam_circle_fit_batch(n, off.ctypes.data_as(_ip), _p(xs) if xs.size else _p(np.zeros(1)),
+                                       _p(ys) if ys.size else _p(np.zeros(1)), _p(cx), _p(cy), _p(rad),
+                                       st.ctypes.data_as(_ip), circ.ctypes.data_as(_ip), _p(sd), device, C.byref(ms)),
+         "circle_fit_batch")
+    return {"cx": cx[:n], "cy": cy[:n], "radius": rad[:n], "status": st[:n], "is_circle": circ[:n].astype(bool),
+            "angle_std": sd[:n], "kernel_ms": ms.value}
 
 
 def _qr(Q, R):

@@ -28,7 +28,8 @@ def _p(a):
 def build_oracle(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present). Building the checker is not using it."""
     if force or not os.path.exists(ORACLE_SO) or (
-            os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "nuslam_oracle.c"))):
+            os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(os.path.join(ORACLE_DIR, f))
+                                              for f in ("nuslam_oracle.c", "circle_fit_oracle.c"))):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/rigid2d/src") and not os.path.exists(REF_SO):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
@@ -72,8 +73,40 @@ def lib():
         L.orc_state.restype = _dp
         L.orc_cov.argtypes = [C.c_void_p]
         L.orc_cov.restype = _dp
+        L.orc_circle_fit.argtypes = [_dp, _dp, C.c_int, _dp, _dp]
+        L.orc_classify_cluster.argtypes = [_dp, _dp, C.c_int, _dp]
+        L.orc_cluster_points.argtypes = [C.POINTER(C.c_float), C.c_double, C.c_double, _dp, _dp, _ip, _ip]
         _lib = L
     return _lib
+
+
+def circle_fit(xs, ys):
+    """circle_fit::circleFit (circle_fit_library.cpp:15-134): (status, centre_x, centre_y, radius)."""
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    work = np.zeros(4 * max(xs.size, 1))
+    out = np.zeros(3)
+    st = lib().orc_circle_fit(_p(xs), _p(ys), xs.size, _p(work), _p(out))
+    return st, out[0], out[1], out[2]
+
+
+def classify_cluster(xs, ys):
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    sd = C.c_double()
+    ok = lib().orc_classify_cluster(_p(xs), _p(ys), xs.size, C.byref(sd))
+    return bool(ok), sd.value
+
+
+def cluster_points(ranges, min_range, max_range):
+    """circle_fit::clusterPoints (circle_fit_library.cpp:136-206) on a 360-ray scan: list of (xs, ys) clusters."""
+    r = np.ascontiguousarray(ranges, dtype=np.float32)
+    assert r.size == 360
+    px = np.zeros(400); py = np.zeros(400); cl = np.zeros(400, dtype=np.int32)
+    ncl = C.c_int()
+    npts = lib().orc_cluster_points(r.ctypes.data_as(C.POINTER(C.c_float)), min_range, max_range, _p(px), _p(py),
+                                    cl.ctypes.data_as(_ip), C.byref(ncl))
+    return [(px[:npts][cl[:npts] == k].copy(), py[:npts][cl[:npts] == k].copy()) for k in range(ncl.value)]
 
 
 def usable_cpus():
