@@ -137,6 +137,10 @@ int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do 
  * association or 16 pending corrections force it): 2 len^2 w bytes per TICK instead of per correction.
  * Results agree with the default eager path to rounding, not bit for bit. */
 int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
+/* Pairing (default on): inside a tick with known ids, consecutive corrections of already-initialised landmarks are
+ * applied two at a time by one pass over the covariance (k_update2) -- same arithmetic, same bits, half the HBM
+ * bytes per correction.  enable = 0 forces one k_update launch per correction. */
+int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
 
 /* ------------------------------------------------------------------ landmark extraction */
@@ -157,7 +161,8 @@ typedef enum {
     NUSLAM_K_DENSE_GEMM = 3,   /* the two MFMA products of nuslam_ekf_predict_dense */
     NUSLAM_K_UPDATE_DEFERRED = 4, /* one correction in factor form, O(len) (deferred mode) */
     NUSLAM_K_FLUSH = 5,        /* the rank-2J pass that applies a tick's pending corrections (deferred mode) */
-    NUSLAM_K_COUNT = 6
+    NUSLAM_K_UPDATE2 = 6,      /* two consecutive corrections in one pass over P (bit-identical to two NUSLAM_K_UPDATE) */
+    NUSLAM_K_COUNT = 7
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

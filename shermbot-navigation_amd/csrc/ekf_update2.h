@@ -1,0 +1,339 @@
+// ekf_update2.h -- TWO consecutive corrections in one pass over the covariance (temporal blocking of k_update).
+//
+// ExtendedKalman::update (slam_library.cpp:263-282) applied twice, for markers i and i+1 of a tick whose landmark ids
+// the host knows: P2 = (I - K2 H2) (I - K1 H1) P0.  Everything the second correction needs from P1 -- its five rows,
+// its five columns and the 5x5 block at {0,1,2,c2,c2+1}, and the state after the first correction -- is a handful of
+// ENTRIES of P1, and each entry of P1 is produced by the same sweep formula from P0, M1 and the prior rows R1.  A wave
+// therefore recomputes those entries itself (from strips of P0 it loads anyway) and applies both corrections to its
+// tile in registers: every element of P is read once and written once per PAIR of corrections -- half the HBM bytes
+// per correction -- and the arithmetic of every entry is exactly the sequential one, operation for operation, so the
+// result is bit-identical to two k_update launches (asserted in tests/test_gpu_pair.py) and hence to the oracle.
+//
+// Restrictions (checked by the host, which falls back to k_update otherwise): known association with ids passed
+// inline, both landmarks already initialised (no initializeLandmark, no skip / break branch).
+#pragma once
+
+namespace nuslam {
+
+// the sweep formula of k_update for one entry: sum_k M(i,k) P(k,j), k ascending over {0,1,2} U {i} U {c,c+1}
+__device__ inline double sweep_entry(const double m[5], const double r[5], double pij, double before, double after)
+{
+    double acc = m[0] * r[0];
+    acc = fma(m[1], r[1], acc);
+    acc = fma(m[2], r[2], acc);
+    acc = fma(before, pij, acc);
+    acc = fma(m[3], r[3], acc);
+    acc = fma(m[4], r[4], acc);
+    acc = fma(after, pij, acc);
+    return acc;
+}
+
+// K(i,:) = (P H^T)(i,:) S^-1 and M(i, set[q]) = delta - (K H)(i, set[q]) from the five column entries pc[q] = P(i, set[q])
+__device__ inline void gain_row(const double pc[5], const double Hc[10], const double Sinv[4], int i, const int set[5],
+                                double K[2], double m[5])
+{
+    double ph[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc = fma(pc[q], Hc[rr + 2 * q], acc);
+        ph[rr] = acc;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        double acc = 0.0;
+        acc = fma(ph[0], Sinv[0 + 2 * s2], acc);
+        acc = fma(ph[1], Sinv[1 + 2 * s2], acc);
+        K[s2] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double kh = 0.0;
+        kh = fma(K[0], Hc[0 + 2 * q], kh);
+        kh = fma(K[1], Hc[1 + 2 * q], kh);
+        m[q] = (i == set[q] ? 1.0 : 0.0) - kh;
+    }
+}
+
+// an entry of P1 as k_update leaves it in memory: rounded to the storage type
+template <typename T>
+__device__ inline double p1_entry(const double m[5], const double r[5], double pij, double before, double after)
+{
+    return (double)(T)sweep_entry(m, r, pij, before, after);
+}
+
+// LDS layout (doubles)
+enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 5x5: M1(set2[a], set1[q]) */,
+       S2_R1S = 53 /* [q][b] 5x5: P0(set1[q], set2[b]) */, S2_DZ1 = 78, S2_ST1 = 80 /* th,x,y,lx2,ly2 after correction 1 */,
+       S2_OBS = 85 /* r1, phi1, r2, phi2 */, S2_K1S = 89 /* [a][2]: K1(set2[a], :) */, S2_WORDS = 100 };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
+                                                 T* __restrict__ Pout)
+{
+    constexpr int CW = 16;
+    typedef Pack16<T> vec_t;
+    constexpr int VEC = 16 / sizeof(T);
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = v.ld, L = v.L;
+    const int row0 = (blockIdx.x * 64 + lane) * VEC;
+    const int strip = blockIdx.y * 4 + wave;
+    const bool active = strip * CW < L;
+    const int j0 = active ? strip * CW : 0;
+    const bool rows_ok = row0 < ld;
+    const int rowc = rows_ok ? row0 : 0;
+    const int ncol = (L - j0) < CW ? (L - j0) : CW;
+
+    __shared__ double sh[S2_WORDS];
+    __shared__ int sh_i[4];                       // singular flag of correction 1, of correction 2, status
+
+    const int c1 = 3 + 2 * (o1.id0 - 1), c2 = 3 + 2 * (o2.id0 - 1);
+    const int set1[5] = { 0, 1, 2, c1, c1 + 1 };
+    const int set2[5] = { 0, 1, 2, c2, c2 + 1 };
+    const int U[7] = { 0, 1, 2, c1, c1 + 1, c2, c2 + 1 };        // set1[q] = U[q]; set2[q] = U[q < 3 ? q : q + 2]
+    const double* s = v.s_in + (size_t)b * ld;
+    double* so = v.s_out + (size_t)b * ld;
+    const T* Pb = Pin + (size_t)b * v.p_stride;
+
+    // ---- one burst of loads
+    double v_blk = 0, v_st = 0;                    // wave 0: lane 7a + b holds P0(U[a], U[b]); lanes 0..6 hold state[U[k]]
+    if (wave == 0) {
+        const int a = lane < 49 ? lane / 7 : 0, bb = lane < 49 ? lane % 7 : 0;
+        v_blk = (double)Pb[(size_t)U[bb] * ld + U[a]];
+        v_st = s[U[lane < 7 ? lane : 0]];
+    }
+    // prior rows of this wave's columns, one element per lane (lane = 16q + jj):
+    //   vA rows {0, 1, 2, c1},  vB rows {c1+1, c2, c2+1, c2+1}
+    const int sj = lane & 15, sq = lane >> 4;
+    const int sjc = sj < ncol ? sj : 0;
+    const T* colp = Pb + (size_t)(j0 + sjc) * ld;
+    const double vA = (double)colp[sq < 3 ? sq : c1];
+    const double vB = (double)colp[sq == 0 ? c1 + 1 : (sq == 1 ? c2 : c2 + 1)];
+    const T* Pr = Pb + (size_t)j0 * ld + rowc;
+    vec_t p[CW];
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) p[jj] = *reinterpret_cast<const vec_t*>(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+    vec_t pcU[7];                                  // columns U[k] of P0 at this lane's rows
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pcU[k] = *reinterpret_cast<const vec_t*>(Pb + (size_t)U[k] * ld + rowc);
+
+    // ---- phase A, four roles in parallel (the transcendental chains need the state and the trace only, not P):
+    //   wave 1: marker 1 in polar form      wave 2: marker 2 in polar form      wave 3: z_hat of correction 1
+    //   wave 0: head of correction 1 (H1, S1^-1) and K1 / M1 at the rows of set2
+    auto blk = [&](int a, int bb) { return lane_bcast(v_blk, 7 * a + bb); };   // P0(U[a], U[b]) (wave 0 only)
+    auto u2 = [](int q) { return q < 3 ? q : q + 2; };                          // index of set2[q] in U
+    double Hc1r[10], Si1r[4], K1s[5][2], M1s[5][5];
+    int sing1 = 0, status = 0;
+    if (wave == 1) {
+        double r1, f1;
+        fetch_obs(o1, b, r1, f1);
+        if (lane == 0) { sh[S2_OBS] = r1; sh[S2_OBS + 1] = f1; }
+    } else if (wave == 2) {
+        double r2, f2;
+        fetch_obs(o2, b, r2, f2);
+        if (lane == 0) { sh[S2_OBS + 2] = r2; sh[S2_OBS + 3] = f2; }
+    } else if (wave == 3) {
+        double zr, zb;
+        measurement(s[0], s[1], s[2], s[c1], s[c1 + 1], zr, zb);       // :265, at the state before correction 1
+        if (lane == 0) { sh[S2_DZ1] = zr; sh[S2_DZ1 + 1] = zb; }
+    } else {
+        const double x = lane_bcast(v_st, 1), y = lane_bcast(v_st, 2);
+        const double l1x = lane_bcast(v_st, 3), l1y = lane_bcast(v_st, 4);
+        status = v.c_in[b * C_WORDS + C_STATUS];
+        double pb[5][5], S[4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = blk(q2, q);     // pb[q][q2] = P(set[q2], set[q])
+        jacobian_compact(x, y, l1x, l1y, Hc1r);
+        innovation_cov_block(pb, Hc1r, v.R, S);
+        sing1 = inv2(S, Si1r);
+        if (sing1) {                                                    // correction 1 becomes a no-op: K1 = 0
+            if (status == 0) status = kStatusSingular;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si1r[q] = 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            double pc[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pc[q] = blk(u2(a), q);          // P0(set2[a], set1[q])
+            gain_row(pc, Hc1r, Si1r, set2[a], set1, K1s[a], M1s[a]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int q = 0; q < 5; ++q) { sh[S2_M1S + 5 * a + q] = M1s[a][q]; sh[S2_R1S + 5 * q + a] = blk(q, u2(a)); }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B, wave 0: first innovation, state after correction 1, head of correction 2
+    if (wave == 0) {
+        const double th = lane_bcast(v_st, 0), x = lane_bcast(v_st, 1), y = lane_bcast(v_st, 2);
+        const double l2x = lane_bcast(v_st, 5), l2y = lane_bcast(v_st, 6);
+        const double dz10 = sing1 ? 0.0 : sh[S2_OBS] - sh[S2_DZ1], dz11 = sing1 ? 0.0 : sh[S2_OBS + 1] - sh[S2_DZ1 + 1];
+        double st1[5];
+        const double s0v[5] = { th, x, y, l2x, l2y };
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            double acc = 0.0;
+            acc = fma(K1s[a][0], dz10, acc);
+            acc = fma(K1s[a][1], dz11, acc);
+            st1[a] = s0v[a] + acc;
+        }
+        if (!sing1) st1[0] = normalize_angle(st1[0]);                  // update() re-normalises the heading (:276)
+        // P1(set2, set2), one entry per lane (lane = 5q + q2: row set2[q2], column set2[q]), exactly as the sweep forms it
+        double ent = 0.0;
+        {
+            const int e = lane < 25 ? lane : 0;
+            const int q = e / 5, q2 = e % 5;
+            double mrow[5], r1v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                mrow[k] = sh[S2_M1S + 5 * q2 + k];                      // written by this wave before the barrier
+                r1v[k] = __shfl(v_blk, 7 * k + u2(q), 64);              // P0(set1[k], set2[q])
+            }
+            const int i = set2[q2];
+            const double bef = (i > 2 && i < c1) ? 1.0 : 0.0, aft = (i > c1 + 1) ? 1.0 : 0.0;
+            ent = p1_entry<T>(mrow, r1v, __shfl(v_blk, 7 * u2(q2) + u2(q), 64), bef, aft);
+        }
+        double Hc2[10], Si2[4], pb[5][5], S[4];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+#pragma unroll
+            for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);
+        jacobian_compact(st1[1], st1[2], st1[3], st1[4], Hc2);         // :268 at the corrected state
+        innovation_cov_block(pb, Hc2, v.R, S);
+        int sing2 = inv2(S, Si2);
+        if (sing2) {
+            if (status == 0) status = kStatusSingular;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si2[q] = 0.0;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) { sh[S2_HC1 + q] = Hc1r[q]; sh[S2_HC2 + q] = Hc2[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sh[S2_SI1 + q] = Si1r[q]; sh[S2_SI2 + q] = Si2[q]; }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) sh[S2_ST1 + a] = st1[a];
+            sh_i[0] = sing1; sh_i[1] = sing2; sh_i[2] = status;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                            // lgkmcnt(0): zr, zb were read by every lane
+        if (lane == 0) { sh[S2_DZ1] = dz10; sh[S2_DZ1 + 1] = dz11; }
+    }
+    __syncthreads();
+    if (!active) return;
+    sing1 = sh_i[0];
+    const int sing2 = sh_i[1];
+    // H and S^-1 of both corrections stay in LDS (wave-uniform broadcast reads): holding 28 doubles per lane in VGPRs
+    // pushed the kernel past 256 registers, i.e. down to one wave per SIMD
+    const double* Hc1 = sh + S2_HC1; const double* Si1 = sh + S2_SI1;
+    const double* Hc2 = sh + S2_HC2; const double* Si2 = sh + S2_SI2;
+    const double dz10 = sh[S2_DZ1], dz11 = sh[S2_DZ1 + 1];
+
+    // the second innovation (atan2 / sin / cos) only feeds the state: column strip 0's waves
+    const bool owns_state = (strip == 0);
+    double dz20 = 0, dz21 = 0;
+    if (owns_state && !sing2) {
+        double zr, zb;
+        measurement(sh[S2_ST1], sh[S2_ST1 + 1], sh[S2_ST1 + 2], sh[S2_ST1 + 3], sh[S2_ST1 + 4], zr, zb);
+        dz20 = sh[S2_OBS + 2] - zr;
+        dz21 = sh[S2_OBS + 3] - zb;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        const int* ci = v.c_in + b * C_WORDS;
+        int* co = v.c_out + b * C_WORDS;
+        co[C_SEEN] = ci[C_SEEN]; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = ci[C_BRK]; co[C_STATUS] = sh_i[2];
+        if (v.id_log && o1.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o1.log_slot] = o1.id0;
+        if (v.id_log && o2.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o2.log_slot] = o2.id0;
+    }
+
+    // ---- this lane's rows: M1, then the columns set2 of P1 at these rows, then M2
+    double m1[VEC][5], m2[VEC][5], bef1[VEC], aft1[VEC], bef2[VEC], aft2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int i = row0 + e;
+        double pc[5], K1[2], K2[2];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pc[q] = (double)pcU[q].v[e];                     // P0(i, set1[q])
+        gain_row(pc, Hc1, Si1, i, set1, K1, m1[e]);
+        bef1[e] = ((i > 2) && (i < c1)) ? 1.0 : 0.0;
+        aft1[e] = (i > c1 + 1) ? 1.0 : 0.0;
+        bef2[e] = ((i > 2) && (i < c2)) ? 1.0 : 0.0;
+        aft2[e] = (i > c2 + 1) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {                                                // P1(i, set2[q])
+            double r1v[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) r1v[k] = sh[S2_R1S + 5 * k + q];
+            pc[q] = p1_entry<T>(m1[e], r1v, (double)pcU[q < 3 ? q : q + 2].v[e], bef1[e], aft1[e]);
+        }
+        gain_row(pc, Hc2, Si2, i, set2, K2, m2[e]);
+        if (owns_state && rows_ok) {
+            // state after both corrections: s + K1 nu1, heading re-normalised, then + K2 nu2, re-normalised (:275-276)
+            double acc = 0.0;
+            acc = fma(K1[0], dz10, acc);
+            acc = fma(K1[1], dz11, acc);
+            double sv = s[i] + acc;
+            if (i == 0 && !sing1) sv = normalize_angle(sv);
+            acc = 0.0;
+            acc = fma(K2[0], dz20, acc);
+            acc = fma(K2[1], dz21, acc);
+            sv = sv + acc;
+            if (i == 0 && !sing2) sv = normalize_angle(sv);
+            so[i] = sv;
+        }
+    }
+
+    // ---- this wave's columns: the rows set2 of P1, lane-distributed like vA / vB (wA rows {0,1,2,c2}, wB row c2+1)
+    double wA, wB;
+    {
+        double r1v[5];
+        r1v[0] = __shfl(vA, sj, 64); r1v[1] = __shfl(vA, 16 + sj, 64); r1v[2] = __shfl(vA, 32 + sj, 64);
+        r1v[3] = __shfl(vA, 48 + sj, 64); r1v[4] = __shfl(vB, sj, 64);
+        const double p0c2 = __shfl(vB, 16 + sj, 64), p0c21 = __shfl(vB, 32 + sj, 64);   // P0(c2, j), P0(c2+1, j)
+        double mrow[5];
+        {
+            const int a = sq;                                        // set2[a], a = 0..3
+#pragma unroll
+            for (int q = 0; q < 5; ++q) mrow[q] = sh[S2_M1S + 5 * a + q];
+            const int i = set2[a];
+            const double bef = (i > 2 && i < c1) ? 1.0 : 0.0, aft = (i > c1 + 1) ? 1.0 : 0.0;
+            wA = p1_entry<T>(mrow, r1v, a < 3 ? vA : p0c2, bef, aft);
+        }
+        {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) mrow[q] = sh[S2_M1S + 5 * 4 + q];
+            const int i = set2[4];
+            const double bef = (i > 2 && i < c1) ? 1.0 : 0.0, aft = (i > c1 + 1) ? 1.0 : 0.0;
+            wB = p1_entry<T>(mrow, r1v, p0c21, bef, aft);
+        }
+    }
+
+    // ---- the sweep: both corrections on the tile in registers
+    T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) {
+        double r1v[5], r2v[5];
+        r1v[0] = lane_bcast(vA, jj); r1v[1] = lane_bcast(vA, 16 + jj); r1v[2] = lane_bcast(vA, 32 + jj);
+        r1v[3] = lane_bcast(vA, 48 + jj); r1v[4] = lane_bcast(vB, jj);
+        r2v[0] = lane_bcast(wA, jj); r2v[1] = lane_bcast(wA, 16 + jj); r2v[2] = lane_bcast(wA, 32 + jj);
+        r2v[3] = lane_bcast(wA, 48 + jj); r2v[4] = lane_bcast(wB, jj);
+        vec_t out;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            // k_update stores P1 in T; with fp32 storage the second correction must start from that rounded value
+            const double p1 = p1_entry<T>(m1[e], r1v, (double)p[jj].v[e], bef1[e], aft1[e]);
+            out.v[e] = (T)sweep_entry(m2[e], r2v, p1, bef2[e], aft2[e]);
+        }
+        if (jj < ncol && rows_ok) *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = out;
+    }
+}
+
+} // namespace nuslam

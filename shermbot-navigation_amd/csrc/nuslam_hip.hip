@@ -66,6 +66,9 @@ struct nuslam_batch {
     void* wF = nullptr;
     bool f_staged = false;
     // deferred application: pending rank-2 factors U_i = K_i, V_i = H_i P_{i-1}
+    bool pairing = true;       // k_update2 for consecutive plain corrections of a known-id tick
+    int host_seen = 0;         // host mirror of `seen` (all filters alike); valid while only known-id calls were made
+    bool host_seen_valid = true;
     bool deferred = false;
     double* dU = nullptr; double* dV = nullptr;
     int J = 0;
@@ -219,6 +222,7 @@ int do_associate(nuslam_batch* h, const ObsArg& o)
 
 int associate_finish(nuslam_batch* h)
 {
+    h->host_seen_valid = false;
     View v = h->view();
     int rc = launch(h, -1, k_associate_finish, dim3(h->B), dim3(1), v);
     if (rc) return rc;
@@ -267,18 +271,50 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     return NUSLAM_OK;
 }
 
+int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
+{
+    View v = h->view();
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
+    if (rc) return rc;
+    h->sidx ^= 1;
+    h->cidx ^= 1;
+    h->pidx ^= 1;
+    return NUSLAM_OK;
+}
+
 // One loop body of slam.cpp:250-319 for every filter of the batch.
 int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
             const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr)
 {
     int rc = do_predict(h, tw);
     if (rc) return rc;
-    for (int i = 0; i < m; ++i) {
+    // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark: then the
+    // caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does not move.
+    bool plain = known && host_ids != nullptr && h->host_seen_valid;
+    if (plain)
+        for (int i = 0; i < m; ++i)
+            if (host_ids[i] < 1 || host_ids[i] > h->n || host_ids[i] > total || host_ids[i] > h->host_seen) { plain = false; break; }
+    const bool pair = plain && h->pairing && !h->deferred;
+    auto obs_at = [&](int i) {
         ObsArg o = base;
         o.off = base.off + i;
         o.log_slot = h->id_log ? i : -1;
         if (host_ids) { o.ids = nullptr; o.id0 = host_ids[i]; }        // same id for every filter: pass it inline
         if (host_mx) { o.a = nullptr; o.b = nullptr; o.a0 = host_mx[i]; o.b0 = host_my[i]; }
+        return o;
+    };
+    for (int i = 0; i < m; ++i) {
+        if (pair && i + 1 < m) {
+            rc = do_update2(h, obs_at(i), obs_at(i + 1));
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
+        ObsArg o = obs_at(i);
         if (!known) {
             rc = do_associate(h, o);
             if (rc) return rc;
@@ -286,6 +322,16 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         rc = do_update(h, o, known ? MODE_KNOWN : MODE_DA, total);
         if (rc) return rc;
     }
+    // keep the host mirror of `seen` exact, or drop it
+    if (!known) h->host_seen_valid = false;
+    else if (host_ids && h->host_seen_valid) {
+        for (int i = 0; i < m; ++i) {
+            const int id = host_ids[i];
+            if (id < 0) continue;                                       // skipped marker
+            if (id < 1 || id > h->n || id > total) { h->host_seen_valid = false; break; }   // error / break paths: stop mirroring
+            if (id > h->host_seen) h->host_seen = id;
+        }
+    } else if (!host_ids) h->host_seen_valid = false;
     return NUSLAM_OK;
 }
 
@@ -372,6 +418,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     if (rc) return rc;
     HIPCHK(e);
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
+    h->host_seen = 0; h->host_seen_valid = true;
     return NUSLAM_OK;
 }
 
@@ -453,6 +500,8 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
+    if (h->B == 1) { h->host_seen = seen; h->host_seen_valid = true; }
+    else h->host_seen_valid = false;
     return NUSLAM_OK;
 }
 
@@ -687,6 +736,13 @@ int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable)
 
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable) { return h ? nuslam_batch_set_deferred(h->core, enable) : NUSLAM_E_ARG; }
 
+int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    h->pairing = enable != 0;
+    return NUSLAM_OK;
+}
+
 int nuslam_batch_profile(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
@@ -764,6 +820,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (rc) return rc;
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
+    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing;
     rc = [&]() -> int {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipStreamSynchronize(s->stream));

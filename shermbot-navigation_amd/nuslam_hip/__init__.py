@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_
 
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
 F64, F32 = 0, 1
-K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH = range(6)
+K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2 = range(7)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -63,6 +63,7 @@ SYMBOLS = [
     ("nuslam_ekf_as_batch", C.c_int, [_vp, _vpp]),
     ("nuslam_batch_set_deferred", C.c_int, [_vp, C.c_int]),
     ("nuslam_ekf_set_deferred", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_set_pairing", C.c_int, [_vp, C.c_int]),
     ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
@@ -263,6 +264,9 @@ class Batch:
 
     def set_deferred(self, enable=True):
         _chk(lib().nuslam_batch_set_deferred(self._h, 1 if enable else 0), "batch_set_deferred")
+
+    def set_pairing(self, enable=True):
+        _chk(lib().nuslam_batch_set_pairing(self._h, 1 if enable else 0), "batch_set_pairing")
 
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")

@@ -1,0 +1,146 @@
+"""k_update2 (two consecutive corrections in one pass over P) must be BIT-IDENTICAL to two k_update launches -- state,
+covariance, seen, status -- for every storage type, for repeated / adjacent / extreme landmark ids, for odd marker
+counts, and it must step aside (fall back to single launches) whenever a marker is not a plain correction."""
+import numpy as np
+import pytest
+
+import _oracle as O
+from nuslam_hip import synth
+
+pytestmark = pytest.mark.gpu
+Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+
+
+def warm_pair_of_filters(hip, n, dtype=0, seed=12345):
+    lm = synth.make_landmarks(n, seed)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
+    bx, by, ids = synth.warmup_observations(lm, seed=seed)
+    o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=ids)
+    gs = []
+    for pairing in (True, False):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+        g.restore(o.state, o.cov, n)
+        g.as_batch().set_pairing(pairing)
+        gs.append(g)
+    return o, gs[0], gs[1], lm
+
+
+def kernel_counts(g, fn):
+    bt = g.as_batch()
+    bt.profile(True)
+    fn()
+    g.sync()
+    n2 = bt.profile_read(g_hip.K_UPDATE2)[1]
+    n1 = bt.profile_read(g_hip.K_UPDATE)[1]
+    bt.profile(False)
+    return n1, n2
+
+
+g_hip = None
+
+
+@pytest.fixture(autouse=True)
+def _bind(hip):
+    global g_hip
+    g_hip = hip
+
+
+@pytest.mark.parametrize("n,m,dtype", [(10, 10, 0), (37, 16, 0), (64, 7, 0), (40, 16, 1), (127, 9, 0)])
+def test_pair_equals_two_singles_bitwise(hip, n, m, dtype):
+    o, gp, gs, lm = warm_pair_of_filters(hip, n, dtype)
+    tr = synth.make_trace(n, 5, m, landmarks=lm)
+    for t in range(tr.ticks):
+        n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False))
+        assert n2 == m // 2 and n1 == m % 2                      # pairs, plus one single for an odd count
+        gs.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+        o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
+        assert np.array_equal(gp.state, gs.state), "tick %d: state differs" % t
+        assert np.array_equal(gp.cov, gs.cov), "tick %d: covariance differs" % t
+    assert gp.seen == gs.seen == o.seen and gp.status() == 0
+    if dtype == 0:
+        err = (np.abs(gp.cov - o.cov) / np.maximum(np.abs(o.cov), 1e-12 * np.abs(o.cov).max())).max()
+        assert err < 1e-6
+
+
+def test_pair_special_id_patterns(hip):
+    """same landmark twice, neighbouring landmarks (overlapping index sets), the first and the last landmark."""
+    n = 12
+    o, gp, gs, lm = warm_pair_of_filters(hip, n)
+    tr = synth.make_trace(n, 1, n, landmarks=lm)
+    by_id = {int(i): k for k, i in enumerate(tr.ids[0])}
+    for ids in ([3, 3], [4, 5], [5, 4], [1, n], [n, 1], [n, n], [1, 2, 1, 2], [7, 8, 9]):
+        k = [by_id[i] for i in ids]
+        mx, my = tr.mx[0][k], tr.my[0][k]
+        gp.tick([0.01, 0.005, 0.0], mx, my, known_ids=ids, want_ids=False)
+        gs.tick([0.01, 0.005, 0.0], mx, my, known_ids=ids, want_ids=False)
+        o.tick(tw=[0.01, 0.005, 0.0], mx=mx, my=my, known_ids=ids)
+        assert np.array_equal(gp.state, gs.state) and np.array_equal(gp.cov, gs.cov), ids
+    assert np.abs(gp.state - o.state).max() < 1e-9
+
+
+def test_pair_logs_ids_and_handles_two_marker_ticks(hip):
+    n = 9
+    o, gp, gs, lm = warm_pair_of_filters(hip, n)
+    tr = synth.make_trace(n, 3, 2, landmarks=lm)
+    for t in range(3):
+        ip = gp.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
+        isg = gs.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
+        assert np.array_equal(ip, isg) and np.array_equal(ip, tr.ids[t])
+        assert np.array_equal(gp.cov, gs.cov)
+
+
+def test_pairing_steps_aside(hip):
+    """a skipped marker, an uninitialised landmark, an id above total_landmarks or data association: single launches."""
+    n = 10
+    o, gp, gs, lm = warm_pair_of_filters(hip, n)
+    tr = synth.make_trace(n, 4, 6, landmarks=lm)
+    ids = tr.ids[0].copy(); ids[2] = -1
+    n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[0], tr.mx[0], tr.my[0], known_ids=ids, want_ids=False))
+    assert n2 == 0 and n1 == 6
+    gs.tick(tr.tw[0], tr.mx[0], tr.my[0], known_ids=ids, want_ids=False)
+    assert np.array_equal(gp.cov, gs.cov)
+    n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[1], tr.mx[1], tr.my[1], known_ids=tr.ids[1], total_landmarks=3, want_ids=False))
+    assert n2 == 0
+    gs.tick(tr.tw[1], tr.mx[1], tr.my[1], known_ids=tr.ids[1], total_landmarks=3, want_ids=False)
+    assert np.array_equal(gp.cov, gs.cov) and np.array_equal(gp.state, gs.state)
+    # a filter that has seen only 4 landmarks: markers of landmarks 5.. initialise -> no pairing in that tick
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    g.restore(o.state, o.cov, 4)
+    n1, n2 = kernel_counts(g, lambda: g.tick(tr.tw[2], tr.mx[2], tr.my[2], known_ids=tr.ids[2], want_ids=False))
+    assert n2 == (0 if (tr.ids[2] > 4).any() else 3)
+    # data association never pairs, and invalidates the host's mirror of `seen` for later ticks
+    gp.restore(gs.state, gs.cov, n - 1)            # one free slot: associateLandmark indexes out of bounds on a full map
+    n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[3], tr.mx[3], tr.my[3], want_ids=False))
+    assert n2 == 0
+    n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[3], tr.mx[3], tr.my[3], known_ids=tr.ids[3], want_ids=False))
+    assert n2 == 0
+
+
+def test_pair_batch_and_full_size(hip):
+    n, m, T, B = 200, 16, 2, 3
+    tr = synth.make_trace(n, T, m)
+    bx, by, ids = synth.warmup_observations(tr.landmarks)
+    res = []
+    for pairing in (True, False):
+        bt = hip.Batch(B, n, Q, R)
+        bt.set_pairing(pairing)
+        bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], ids[None, :], bcast=True)
+        bt.run(0, 1)
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+        bt.run(0, T)
+        res.append((bt.state(B - 1), bt.cov(B - 1)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # N = 1000 (BASELINE configs[1])
+    n = 1000
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, 2, 16, landmarks=lm)
+    bx, by, ids = synth.warmup_observations(lm)
+    out = []
+    for pairing in (True, False):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+        g.as_batch().set_pairing(pairing)
+        g.tick(np.zeros(3), bx, by, known_ids=ids, want_ids=False)
+        for t in range(2):
+            g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+        out.append((g.state, g.cov))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
