@@ -52,6 +52,7 @@ def parse():
                     help="torch.distributed backend for the batch reduction (nccl = RCCL over xGMI; gloo only to rehearse "
                          "the multi-rank path on one GPU)")
     ap.add_argument("--no-pairing", action="store_true", help="one k_update launch per correction (disable k_update2)")
+    ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="attach the per-dispatch HIP events inside the timed region itself (costs ~25%% throughput: "
                          "every dispatch then carries a completion signal); default: a second pass of K identical steps "
@@ -200,6 +201,8 @@ def main():
         bt.set_deferred(True)
     if args.no_pairing:
         bt.set_pairing(False)
+    elif args.group:
+        bt.set_pairing(args.group)
 
     def barrier():
         if world > 1:

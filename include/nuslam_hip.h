@@ -139,7 +139,8 @@ int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do 
 int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
 /* Pairing (default on): inside a tick with known ids, consecutive corrections of already-initialised landmarks are
  * applied two at a time by one pass over the covariance (k_update2) -- same arithmetic, same bits, half the HBM
- * bytes per correction.  enable = 0 forces one k_update launch per correction. */
+ * bytes per correction.  enable = 0 forces one k_update launch per correction; enable = 4 selects the experimental
+ * four-per-pass kernel (k_updatej, also bit-identical, currently slower than pairs). */
 int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
 

@@ -267,4 +267,5 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 
 #include "ekf_update.h"
 #include "ekf_update2.h"
+#include "ekf_updatej.h"
 #include "ekf_deferred.h"

@@ -66,7 +66,8 @@ struct nuslam_batch {
     void* wF = nullptr;
     bool f_staged = false;
     // deferred application: pending rank-2 factors U_i = K_i, V_i = H_i P_{i-1}
-    bool pairing = true;       // k_update2 for consecutive plain corrections of a known-id tick
+    bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
+    int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
     int host_seen = 0;         // host mirror of `seen` (all filters alike); valid while only known-id calls were made
     bool host_seen_valid = true;
     bool deferred = false;
@@ -286,6 +287,33 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
     return NUSLAM_OK;
 }
 
+// J consecutive plain corrections in one pass (k_updatej); markers i .. i+J-1 of the tick
+template <int J>
+int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, const double* host_mx, const double* host_my)
+{
+    View v = h->view();
+    ObsJ o;
+    o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
+    o.stride = base.stride; o.off = base.off + i;
+    for (int s = 0; s < 4; ++s) {
+        o.a0[s] = (host_mx && s < J) ? host_mx[i + s] : 0.0;
+        o.b0[s] = (host_my && s < J) ? host_my[i + s] : 0.0;
+        o.id[s] = s < J ? host_ids[i + s] : 1;
+    }
+    o.cartesian = base.cartesian;
+    o.log_slot = h->id_log ? i : -1;
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_updatej<T, J>, grid, block, v, o, (const T*)h->P(), (T*)h->Palt())));
+    if (rc) return rc;
+    h->sidx ^= 1;
+    h->cidx ^= 1;
+    h->pidx ^= 1;
+    return NUSLAM_OK;
+}
+
 // One loop body of slam.cpp:250-319 for every filter of the batch.
 int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
             const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr)
@@ -308,8 +336,14 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         return o;
     };
     for (int i = 0; i < m; ++i) {
+        if (pair && h->group >= 4 && i + 3 < m) {
+            rc = do_updatej<4>(h, base, i, host_ids, host_mx, host_my);
+            if (rc) return rc;
+            i += 3;
+            continue;
+        }
         if (pair && i + 1 < m) {
-            rc = do_update2(h, obs_at(i), obs_at(i + 1));
+            rc = h->group == 3 ? do_updatej<2>(h, base, i, host_ids, host_mx, host_my) : do_update2(h, obs_at(i), obs_at(i + 1));
             if (rc) return rc;
             ++i;
             continue;
@@ -740,6 +774,7 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
     h->pairing = enable != 0;
+    if (enable >= 2) h->group = enable;          // 2: two per pass, 4: four per pass
     return NUSLAM_OK;
 }
 
@@ -820,7 +855,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (rc) return rc;
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
-    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing;
+    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group;
     rc = [&]() -> int {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipStreamSynchronize(s->stream));

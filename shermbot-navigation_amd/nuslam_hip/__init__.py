@@ -266,7 +266,8 @@ class Batch:
         _chk(lib().nuslam_batch_set_deferred(self._h, 1 if enable else 0), "batch_set_deferred")
 
     def set_pairing(self, enable=True):
-        _chk(lib().nuslam_batch_set_pairing(self._h, 1 if enable else 0), "batch_set_pairing")
+        """False / True, or the number of corrections per pass (2 or 4)."""
+        _chk(lib().nuslam_batch_set_pairing(self._h, int(enable)), "batch_set_pairing")
 
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")

@@ -11,7 +11,16 @@ pytestmark = pytest.mark.gpu
 Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
 
 
-def warm_pair_of_filters(hip, n, dtype=0, seed=12345):
+GROUPS = [2, 3, 4]        # 2: k_update2; 3: k_updatej<2> (same work through the generic kernel); 4: k_updatej<4>
+
+
+def expected_launches(m, group):
+    if group == 4:
+        return m // 4 + (m % 4) // 2, m % 2
+    return m // 2, m % 2
+
+
+def warm_pair_of_filters(hip, n, dtype=0, seed=12345, group=2):
     lm = synth.make_landmarks(n, seed)
     o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
     bx, by, ids = synth.warmup_observations(lm, seed=seed)
@@ -20,7 +29,7 @@ def warm_pair_of_filters(hip, n, dtype=0, seed=12345):
     for pairing in (True, False):
         g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
         g.restore(o.state, o.cov, n)
-        g.as_batch().set_pairing(pairing)
+        g.as_batch().set_pairing(group if pairing else 0)
         gs.append(g)
     return o, gs[0], gs[1], lm
 
@@ -45,13 +54,14 @@ def _bind(hip):
     g_hip = hip
 
 
+@pytest.mark.parametrize("group", GROUPS)
 @pytest.mark.parametrize("n,m,dtype", [(10, 10, 0), (37, 16, 0), (64, 7, 0), (40, 16, 1), (127, 9, 0)])
-def test_pair_equals_two_singles_bitwise(hip, n, m, dtype):
-    o, gp, gs, lm = warm_pair_of_filters(hip, n, dtype)
+def test_pair_equals_two_singles_bitwise(hip, n, m, dtype, group):
+    o, gp, gs, lm = warm_pair_of_filters(hip, n, dtype, group=group)
     tr = synth.make_trace(n, 5, m, landmarks=lm)
     for t in range(tr.ticks):
         n1, n2 = kernel_counts(gp, lambda: gp.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False))
-        assert n2 == m // 2 and n1 == m % 2                      # pairs, plus one single for an odd count
+        assert (n2, n1) == expected_launches(m, group)           # groups, pairs, plus one single for an odd count
         gs.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
         o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
         assert np.array_equal(gp.state, gs.state), "tick %d: state differs" % t
@@ -62,13 +72,15 @@ def test_pair_equals_two_singles_bitwise(hip, n, m, dtype):
         assert err < 1e-6
 
 
-def test_pair_special_id_patterns(hip):
+@pytest.mark.parametrize("group", GROUPS)
+def test_pair_special_id_patterns(hip, group):
     """same landmark twice, neighbouring landmarks (overlapping index sets), the first and the last landmark."""
     n = 12
-    o, gp, gs, lm = warm_pair_of_filters(hip, n)
+    o, gp, gs, lm = warm_pair_of_filters(hip, n, group=group)
     tr = synth.make_trace(n, 1, n, landmarks=lm)
     by_id = {int(i): k for k, i in enumerate(tr.ids[0])}
-    for ids in ([3, 3], [4, 5], [5, 4], [1, n], [n, 1], [n, n], [1, 2, 1, 2], [7, 8, 9]):
+    for ids in ([3, 3], [4, 5], [5, 4], [1, n], [n, 1], [n, n], [1, 2, 1, 2], [7, 8, 9], [5, 5, 5, 5], [1, n, 2, n - 1],
+                [3, 4, 3, 4, 6], [n, n - 1, n - 2, n - 3, 1, 2, 3, 4]):
         k = [by_id[i] for i in ids]
         mx, my = tr.mx[0][k], tr.my[0][k]
         gp.tick([0.01, 0.005, 0.0], mx, my, known_ids=ids, want_ids=False)
@@ -121,7 +133,7 @@ def test_pair_batch_and_full_size(hip):
     tr = synth.make_trace(n, T, m)
     bx, by, ids = synth.warmup_observations(tr.landmarks)
     res = []
-    for pairing in (True, False):
+    for pairing in (4, False, 2):
         bt = hip.Batch(B, n, Q, R)
         bt.set_pairing(pairing)
         bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], ids[None, :], bcast=True)
@@ -130,13 +142,14 @@ def test_pair_batch_and_full_size(hip):
         bt.run(0, T)
         res.append((bt.state(B - 1), bt.cov(B - 1)))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[2][0], res[1][0]) and np.array_equal(res[2][1], res[1][1])
     # N = 1000 (BASELINE configs[1])
     n = 1000
     lm = synth.make_landmarks(n)
     tr = synth.make_trace(n, 2, 16, landmarks=lm)
     bx, by, ids = synth.warmup_observations(lm)
     out = []
-    for pairing in (True, False):
+    for pairing in (4, False):
         g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
         g.as_batch().set_pairing(pairing)
         g.tick(np.zeros(3), bx, by, known_ids=ids, want_ids=False)
