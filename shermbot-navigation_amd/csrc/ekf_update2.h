@@ -316,15 +316,23 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
         }
     }
 
-    // ---- the sweep: both corrections on the tile in registers
+    // ---- the sweep: both corrections on the tile in registers.  The ten prior-row values of a column (R1, R2) are
+    // wave-uniform; they go through a per-wave LDS strip and come back as broadcast ds_read_b128 -- 5 LDS reads per
+    // column instead of 20 v_readlane, which were a sixth of this kernel's VALU instructions.
+    __shared__ double sR[4][CW][10];
+    {
+        double(*R)[10] = sR[wave];
+        R[sj][sq] = vA;                               // r1[0..3] = rows 0, 1, 2, c1
+        R[sj][5 + sq] = wA;                           // r2[0..3] = rows 0, 1, 2, c2 of P1
+        if (sq == 0) { R[sj][4] = vB; R[sj][9] = wB; }    // r1[4] = row c1+1, r2[4] = row c2+1 of P1
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the strip is this wave's own, no barrier needed
     T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj) {
         double r1v[5], r2v[5];
-        r1v[0] = lane_bcast(vA, jj); r1v[1] = lane_bcast(vA, 16 + jj); r1v[2] = lane_bcast(vA, 32 + jj);
-        r1v[3] = lane_bcast(vA, 48 + jj); r1v[4] = lane_bcast(vB, jj);
-        r2v[0] = lane_bcast(wA, jj); r2v[1] = lane_bcast(wA, 16 + jj); r2v[2] = lane_bcast(wA, 32 + jj);
-        r2v[3] = lane_bcast(wA, 48 + jj); r2v[4] = lane_bcast(wB, jj);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { r1v[q] = sR[wave][jj][q]; r2v[q] = sR[wave][jj][5 + q]; }
         vec_t out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
