@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the batch reduction (nccl = RCCL over xGMI; gloo only to rehearse "
                          "the multi-rank path on one GPU)")
+    ap.add_argument("--trace", default=None, choices=["host", "device"],
+                    help="batch workload: per-filter Monte-Carlo traces generated on the device by the simulator kernels "
+                         "(default), or one host-made trace per rank replayed by every filter")
     ap.add_argument("--no-pairing", action="store_true", help="one k_update launch per correction (disable k_update2)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
     ap.add_argument("--events-in-timed-region", action="store_true",
@@ -196,7 +199,21 @@ def main():
         bt.sync()
         warm_state = None
     ids = tr.ids if known else None
-    bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
+    trace_kind = args.trace or ("device" if args.workload == "batch" else "host")
+    if trace_kind == "device":
+        # every filter is its own Monte-Carlo trial -- its trace is generated in HBM by the simulator
+        # kernels (tube_world.cpp:509-533 per filter) from the random streams of its GLOBAL filter index, so the
+        # sharded run reproduces the unsharded one and nothing but the six-number parameter block crosses PCIe
+        ticks_total = W + 3 * K
+        uL, uR = 0.30 * 50, 0.36 * 50                      # the wheel increments of synth.make_trace, per second
+        cmd = np.zeros((ticks_total, 2))
+        cmd[:, 0] = (synth.WHEEL_RADIUS / synth.WHEEL_BASE) * (uR - uL)
+        cmd[:, 1] = (synth.WHEEL_RADIUS / 2) * (uL + uR)
+        cmd[24::25, 0] = 0.0                               # every 25th tick straight: the dth == 0 branch
+        sim = nh.SimParams(marker_sigma=float(np.sqrt(1e-3)) if known else 1e-4, max_range=0.0)
+        bt.simulate(sim, tr.landmarks, cmd, m, 12345, first_filter=rank * B, known_ids=known)
+    else:
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
     if args.deferred:
         bt.set_deferred(True)
     if args.no_pairing:
@@ -288,6 +305,8 @@ def main():
                                 "ekf5000": "single EKF per GPU, fp32, dense MFMA F P F^T predict (BASELINE configs[2])"}[args.workload],
                    "landmarks": n, "state_len": L, "filters_per_gpu": B, "filters_total": n_filters_total,
                    "updates_per_step": m, "parallelism": "replicas x%d" % world if B == 1 else "filters sharded x%d" % world,
+                   "trace": "per-filter, generated on the device (k_sim_path / k_sim_markers)" if trace_kind == "device"
+                            else "one host-made trace per rank, resident in HBM",
                    "kernel_events_in_timed_region": in_region, "Q_diag": float(Q[0, 0]), "R_diag": float(R[0, 0])},
         "ticks_per_s": float(world) * B * K / dt,
     }

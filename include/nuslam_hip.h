@@ -57,6 +57,10 @@ int nuslam_cartesian2polar(double x, double y, double out_range_bearing[2]);
 int nuslam_measurement(const double* state, int len, int j, double out_range_bearing[2]);
 /* ExtendedKalman::linearizedMeasurementModel(j, state_vec), slam_library.cpp:162-186; H is 2 x len, ld 2 */
 int nuslam_jacobian(const double* state, int len, int j, double* H);
+/* The map -> odom transform the slam node broadcasts every tick, EKFSlam::broadcast_map2odom_tf, slam.cpp:175-210:
+ * T_mo = T_mb * T_ob^-1 with T_mb from the filter's pose (state[0..2] = theta, x, y) and T_ob from the odometry
+ * model's pose odom = {x, y, theta}; out = {x, y, yaw}, yaw = normalize_angle(asin(sin theta_mo)) (:194). */
+int nuslam_map_to_odom(const double odom_xyth[3], const double state[3], double out_xyyaw[3]);
 
 /* ------------------------------------------------------------------ one filter */
 /* ExtendedKalman(colvec robotState, colvec mapState, mat Q, mat R), slam_library.cpp:39-63 (+ initCov :24-33).
@@ -143,6 +147,37 @@ int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
  * four-per-pass kernel (k_updatej, also bit-identical, currently slower than pairs). */
 int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
+
+/* ------------------------------------------------------------------ Monte-Carlo trace generator */
+/* The simulator's loop, nuturtlesim/src/tube_world.cpp:509-533, run on the device for every filter of a batch and
+ * written straight into the resident trace nuslam_batch_run() replays -- per-filter worlds without host involvement.
+ * Parameter names and defaults follow nuturtlesim/config/tube_world_params.yaml and
+ * nuturtle_description/config/diff_params.yaml. */
+typedef struct nuslam_sim_params {
+    double wheel_base, wheel_radius;   /* diff_params.yaml:2-3 */
+    double dt;                         /* loop period, 1 / frequency (tube_world.cpp:66: 50 Hz) */
+    double twist_noise;                /* sigma of the Gaussian added to the commanded dth and dx, :177-189 */
+    double slip_min, slip_max;         /* wheel-slip noise N((min + max) / 2, max - mean), :480-483 */
+    double tube_radius, robot_radius;  /* collision slide, :371-389 */
+    double tube_var;                   /* constant offset added to both marker coordinates, :311-312 */
+    double marker_sigma;               /* extension: Gaussian marker noise on top (0 = the reference's behaviour) */
+    double max_range;                  /* range gate :300-307; <= 0: every tube every tick (what the slam node sees) */
+} nuslam_sim_params;
+/* Generate `ticks` ticks for every filter: landmarks = {x0, y0, x1, y1, ...} (n_world tubes, shared by all filters),
+ * cmd = ticks x (dth, dx) commanded body twists (the /cmd_vel stream, shared).  Filter b draws from the random streams
+ * of global filter index first_filter + b, so a sharded batch reproduces the unsharded one.  Each tick keeps the (at
+ * most m) nearest tubes within max_range in tube order; unused slots get id -1, which the tick's decision chain skips
+ * (slam.cpp:298-300).  known_ids != 0: the trace carries the tube index + 1 as the landmark id; 0: data association
+ * (then every slot must be filled: NUSLAM_E_ARG if one is not).  empty_slots (may be NULL) receives the number of
+ * unused slots.  Synchronises. */
+int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
+                          const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
+                          int known_ids, long long* empty_slots);
+/* Read filter b's resident trace back (any pointer may be NULL): tw ticks x 2, mx / my / ids ticks x m, truth
+ * ticks x 3 (theta, x, y of the simulated robot after each tick; only for generated traces). */
+int nuslam_batch_get_trace(nuslam_batch_t* h, int b, double* tw, double* mx, double* my, int* ids, double* truth);
+/* bit-exact hook for the generator's RNG: the Philox4x32-10 block of (seed, counter), computed on the device */
+int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4], int device);
 
 /* ------------------------------------------------------------------ landmark extraction */
 /* circle_fit::circleFit (nuslam/src/circle_fit_library.cpp:15-134) and circle_fit::classifyCluster (:208-250) for a

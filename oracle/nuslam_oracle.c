@@ -70,6 +70,29 @@ static void tf_mul(const double L[4], const double Rr[4], double out[4]) /* rigi
     out[0] = m00; out[1] = m10; out[2] = m02; out[3] = m12;
 }
 
+void orc_tf_make(double x, double y, double rad, double T[4])  /* Transform2D(trans, radians), rigid2d.cpp:170-176 */
+{ T[0] = cos(rad); T[1] = sin(rad); T[2] = x; T[3] = y; }
+void orc_tf_inv(const double T[4], double out[4]) { tf_inv(T, out); }
+void orc_tf_mul(const double L[4], const double Rr[4], double out[4]) { tf_mul(L, Rr, out); }
+void orc_tf_point(const double T[4], double x, double y, double out[2]) /* rigid2d.cpp:178-185 */
+{
+    out[0] = (x * T[0]) + (y * (-T[1])) + T[2];
+    out[1] = (x * T[1]) + (y * T[0]) + T[3];
+}
+
+/* broadcast_map2odom_tf, nuslam/src/slam.cpp:175-210 */
+void orc_map_to_odom(const double odom[3], const double state[3], double out[3])
+{
+    double T_ob[4], T_mb[4], T_bo[4], T_mo[4];
+    orc_tf_make(odom[0], odom[1], odom[2], T_ob);          /* :179-182 */
+    orc_tf_make(state[1], state[2], state[0], T_mb);       /* :186-188 */
+    tf_inv(T_ob, T_bo);
+    tf_mul(T_mb, T_bo, T_mo);                              /* :191 */
+    out[0] = T_mo[2];
+    out[1] = T_mo[3];
+    out[2] = orc_normalize_angle(asin(T_mo[1]));           /* :194 */
+}
+
 /* Transform2D::operator()(Twist2D) -- the adjoint, rigid2d.cpp:254-261.  tw = {dth, dx, dy}. */
 void orc_transform_twist(const double T[4], const double tw[3], double out[3])
 {

@@ -45,6 +45,15 @@ enum { ORC_OK = 0, ORC_E_ARG = 1, ORC_E_BOUNDS = 2, ORC_E_SINGULAR = 3 };
 typedef struct orc_ekf orc_ekf;
 
 /* ---- rigid2d (rigid2d/src/rigid2d.cpp) ---- */
+/* Transform2D as {cos, sin, x, y} (rigid2d.hpp:171-175) */
+void   orc_tf_make(double x, double y, double rad, double T[4]);          /* ctor rigid2d.cpp:170-176 */
+void   orc_tf_inv(const double T[4], double out[4]);                      /* rigid2d.cpp:187-196 */
+void   orc_tf_mul(const double L[4], const double R[4], double out[4]);   /* rigid2d.cpp:198-209, :276-280 */
+void   orc_tf_point(const double T[4], double x, double y, double out[2]); /* operator()(Vector2D), rigid2d.cpp:178-185 */
+/* the map -> odom transform the slam node broadcasts every tick, slam.cpp:175-210:
+ * T_mo = T_mb * T_ob^-1 with T_mb from the filter's pose (state[0..2] = th, x, y) and T_ob from the odometry
+ * model (odom = {x, y, th}); out = {x, y, yaw} with yaw = normalize_angle(asin(sin th)) (:194). */
+void   orc_map_to_odom(const double odom[3], const double state[3], double out[3]);
 double orc_normalize_angle(double rad);                               /* rigid2d.cpp:9-13 */
 void   orc_transform_twist(const double T[4], const double tw[3], double out[3]); /* :254-261; T = {cos,sin,x,y} */
 void   orc_integrate_twist(const double tw[3], double T_out[4]);      /* rigid2d.cpp:294-328 */
@@ -80,6 +89,28 @@ int   orc_update(orc_ekf* e, double r, double phi, int id);            /* :263-2
 int   orc_tick(orc_ekf* e, double dd[7], double thL, double thR, const double* tw_override,
                int m, const double* mx, const double* my, const int* known_ids,
                int total_landmarks, int* ids_out);
+
+/* ---- on-device Monte-Carlo trace generator's checker (nuturtlesim/src/tube_world.cpp, see sim_oracle.c) ---- */
+typedef struct {
+    double wheel_base, wheel_radius;   /* nuturtle_description/config/diff_params.yaml:2-3 */
+    double dt;                         /* 1 / frequency (tube_world.cpp:66: 50 Hz), the ideal loop period */
+    double twist_noise;                /* sigma of the Gaussian added to the commanded dth and dx, :177-189 */
+    double slip_min, slip_max;         /* wheel-slip noise N((min+max)/2, max - mean), :480-483 */
+    double tube_radius, robot_radius;  /* collision slide, :371-389 */
+    double tube_var;                   /* constant offset added to both marker coordinates, :311-312 */
+    double marker_sigma;               /* extension: Gaussian marker noise on top (0 = the reference's behaviour) */
+    double max_range;                  /* range gate :300-307; <= 0 disables it (the slam node ignores DELETE) */
+} orc_sim_params;
+void   orc_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4]);
+void   orc_sim_normal_pair(unsigned long long seed, unsigned filter, unsigned tick, unsigned stream, unsigned idx,
+                           double z[2]);
+/* One filter's trace of `ticks` ticks.  landmarks = {x0, y0, x1, y1, ...}; cmd = ticks x (dth, dx) commanded body
+ * twists.  Outputs (any may be NULL): tw ticks x 2 (what DiffDrive::getTwist gives the slam node, slam.cpp:264),
+ * mx/my/ids ticks x m (robot-frame markers, 1-based landmark index or -1 for an empty slot), truth ticks x 3
+ * (th, x, y), joints ticks x 2.  Returns the number of empty marker slots, or -1 on bad arguments. */
+long long orc_simulate(const orc_sim_params* p, const double* landmarks, int n, const double* cmd, int ticks, int m,
+                       unsigned long long seed, unsigned filter, double* tw, double* mx, double* my, int* ids,
+                       double* truth, double* joints);
 
 int     orc_len(const orc_ekf* e);
 int     orc_n(const orc_ekf* e);

@@ -60,4 +60,30 @@ void ref_dd_step(double dd[7], double thL, double thR)
     dd[2] = d.getX(); dd[3] = d.getY(); dd[4] = d.getTh(); dd[5] = d.getThL(); dd[6] = d.getThR();
 }
 
+// Transform2D algebra: T = {cos, sin, x, y} built through the reference's (trans, radians) constructor
+static rigid2d::Transform2D tf(double x, double y, double rad)
+{
+    rigid2d::Vector2D v; v.x = x; v.y = y;
+    return rigid2d::Transform2D(v, rad);
+}
+static void put(const rigid2d::Transform2D& T, double out[4])
+{ out[0] = T.getCosTh(); out[1] = T.getSinTh(); out[2] = T.getX(); out[3] = T.getY(); }
+
+void ref_tf_inv(double x, double y, double rad, double out[4]) { put(tf(x, y, rad).inv(), out); }
+void ref_tf_mul(double x1, double y1, double rad1, double x2, double y2, double rad2, double out[4])
+{ put(tf(x1, y1, rad1) * tf(x2, y2, rad2), out); }
+void ref_tf_point(double x, double y, double rad, double px, double py, double out[2])
+{
+    rigid2d::Vector2D p; p.x = px; p.y = py;
+    rigid2d::Vector2D q = tf(x, y, rad)(p);
+    out[0] = q.x; out[1] = q.y;
+}
+// the algebra of broadcast_map2odom_tf (nuslam/src/slam.cpp:179-194) on the reference's own Transform2D
+void ref_map_to_odom(const double odom[3], const double state[3], double out[3])
+{
+    rigid2d::Transform2D T_mo = tf(state[1], state[2], state[0]) * tf(odom[0], odom[1], odom[2]).inv();
+    out[0] = T_mo.getX(); out[1] = T_mo.getY();
+    out[2] = rigid2d::normalize_angle(asin(T_mo.getSinTh()));
+}
+
 }

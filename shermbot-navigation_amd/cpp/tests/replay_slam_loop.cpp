@@ -3,7 +3,8 @@
 // cartesian2polar -> associateLandmark -> initializeLandmark / skip / stop -> update.
 //
 // stdin : n total_landmarks ticks m wheel_base wheel_radius, then per tick: thL thR followed by m (x y) pairs
-// stdout: per tick "T seen th x y", at the end "S <len state values>" and "P <len*len covariance, column-major>"
+// stdout: per tick "T seen th x y" and "M x y yaw" (map -> odom, slam.cpp:175-210), at the end "S <len state values>" and "P <len*len covariance, column-major>"
+#include <cmath>
 #include <cstdio>
 #include <iostream>
 #include <vector>
@@ -47,6 +48,15 @@ int main()
             }
             const colvec& s = extended_kalman_filter.getStateVector();
             std::printf("T %d %.17g %.17g %.17g\n", extended_kalman_filter.getSeenLandmarks(), s(0), s(1), s(2));
+            // the map -> odom transform the node broadcasts at the top of its next iteration, slam.cpp:175-210
+            rigid2d::Vector2D v;
+            v.x = odom_model.getX(); v.y = odom_model.getY();
+            const rigid2d::Transform2D T_ob(v, odom_model.getTh());
+            v.x = s(1); v.y = s(2);
+            const rigid2d::Transform2D T_mb(v, s(0));
+            const rigid2d::Transform2D T_mo = T_mb * T_ob.inv();
+            std::printf("M %.17g %.17g %.17g\n", T_mo.getX(), T_mo.getY(),
+                        rigid2d::normalize_angle(std::asin(T_mo.getSinTh())));
         }
     } catch (const std::logic_error& e) {
         std::printf("E logic_error %s\n", e.what());

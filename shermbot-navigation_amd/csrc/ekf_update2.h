@@ -9,8 +9,9 @@
 // per correction -- and the arithmetic of every entry is exactly the sequential one, operation for operation, so the
 // result is bit-identical to two k_update launches (asserted in tests/test_gpu_pair.py) and hence to the oracle.
 //
-// Restrictions (checked by the host, which falls back to k_update otherwise): known association with ids passed
-// inline, both landmarks already initialised (no initializeLandmark, no skip / break branch).
+// Restrictions (checked by the host, which falls back to k_update otherwise): known association with ids the host
+// holds (inline, or per filter in the resident trace), both landmarks already initialised in every filter (no
+// initializeLandmark, no skip / break branch).
 #pragma once
 
 namespace nuslam {
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
     __shared__ double sh[S2_WORDS];
     __shared__ int sh_i[4];                       // singular flag of correction 1, of correction 2, status
 
-    const int c1 = 3 + 2 * (o1.id0 - 1), c2 = 3 + 2 * (o2.id0 - 1);
+    // ids: inline when every filter corrects the same landmarks, else this filter's entries of the resident trace
+    const int id1 = o1.ids ? o1.ids[b * o1.stride + o1.off] : o1.id0;
+    const int id2 = o2.ids ? o2.ids[b * o2.stride + o2.off] : o2.id0;
+    const int c1 = 3 + 2 * (id1 - 1), c2 = 3 + 2 * (id2 - 1);
     const int set1[5] = { 0, 1, 2, c1, c1 + 1 };
     const int set2[5] = { 0, 1, 2, c2, c2 + 1 };
     const int U[7] = { 0, 1, 2, c1, c1 + 1, c2, c2 + 1 };        // set1[q] = U[q]; set2[q] = U[q < 3 ? q : q + 2]
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
         const int* ci = v.c_in + b * C_WORDS;
         int* co = v.c_out + b * C_WORDS;
         co[C_SEEN] = ci[C_SEEN]; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = ci[C_BRK]; co[C_STATUS] = sh_i[2];
-        if (v.id_log && o1.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o1.log_slot] = o1.id0;
-        if (v.id_log && o2.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o2.log_slot] = o2.id0;
+        if (v.id_log && o1.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o1.log_slot] = id1;
+        if (v.id_log && o2.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o2.log_slot] = id2;
     }
 
     // ---- this lane's rows: M1, then the columns set2 of P1 at these rows, then M2

@@ -6,6 +6,7 @@
 #include "../../include/nuslam_hip.h"
 #include "ekf_kernels.h"
 #include "dense_predict.h"
+#include "ekf_sim.h"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -58,7 +59,9 @@ struct nuslam_batch {
     // resident trace
     double* tr_tw = nullptr; double* tr_mx = nullptr; double* tr_my = nullptr; int* tr_ids = nullptr;
     int tr_ticks = 0, tr_m = 0, tr_bcast = 0;
+    double* tr_truth = nullptr;   // generated traces only: the simulated robot's pose after each tick
     std::vector<int> h_ids;    // host copy of a broadcast trace's ids: passed inline so k_update needs no id load
+    std::vector<int> h_ids_pf; // host copy of a per-filter trace's ids [B][ticks][m]: only to decide pairing per tick
     // staging for nuslam_ekf_tick (one filter, m observations)
     double* st_mx = nullptr; double* st_my = nullptr; int* st_ids = nullptr; int* id_log = nullptr;
     int st_cap = 0, log_stride = 0;
@@ -68,7 +71,7 @@ struct nuslam_batch {
     // deferred application: pending rank-2 factors U_i = K_i, V_i = H_i P_{i-1}
     bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
     int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
-    int host_seen = 0;         // host mirror of `seen` (all filters alike); valid while only known-id calls were made
+    std::vector<int> host_seen;   // host mirror of every filter's `seen`; valid while only known-id calls were made
     bool host_seen_valid = true;
     bool deferred = false;
     double* dU = nullptr; double* dV = nullptr;
@@ -316,16 +319,23 @@ int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, 
 
 // One loop body of slam.cpp:250-319 for every filter of the batch.
 int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
-            const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr)
+            const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr,
+            const int* pf_ids = nullptr, long long pf_stride = 0)
 {
     int rc = do_predict(h, tw);
     if (rc) return rc;
-    // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark: then the
-    // caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does not move.
-    bool plain = known && host_ids != nullptr && h->host_seen_valid;
+    // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark, in every
+    // filter: then the caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does
+    // not move.  host_ids: one id list for all filters; pf_ids: filter b's list at pf_ids + b * pf_stride.
+    auto id_of = [&](int b, int i) { return host_ids ? host_ids[i] : pf_ids[(size_t)b * pf_stride + i]; };
+    const bool have_ids = host_ids != nullptr || pf_ids != nullptr;
+    bool plain = known && have_ids && h->host_seen_valid;
     if (plain)
-        for (int i = 0; i < m; ++i)
-            if (host_ids[i] < 1 || host_ids[i] > h->n || host_ids[i] > total || host_ids[i] > h->host_seen) { plain = false; break; }
+        for (int b = 0; b < h->B && plain; ++b)
+            for (int i = 0; i < m; ++i) {
+                const int id = id_of(b, i);
+                if (id < 1 || id > h->n || id > total || id > h->host_seen[b]) { plain = false; break; }
+            }
     const bool pair = plain && h->pairing && !h->deferred;
     auto obs_at = [&](int i) {
         ObsArg o = base;
@@ -336,14 +346,15 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         return o;
     };
     for (int i = 0; i < m; ++i) {
-        if (pair && h->group >= 4 && i + 3 < m) {
+        if (pair && host_ids && h->group >= 4 && i + 3 < m) {
             rc = do_updatej<4>(h, base, i, host_ids, host_mx, host_my);
             if (rc) return rc;
             i += 3;
             continue;
         }
         if (pair && i + 1 < m) {
-            rc = h->group == 3 ? do_updatej<2>(h, base, i, host_ids, host_mx, host_my) : do_update2(h, obs_at(i), obs_at(i + 1));
+            rc = (h->group == 3 && host_ids) ? do_updatej<2>(h, base, i, host_ids, host_mx, host_my)
+                                             : do_update2(h, obs_at(i), obs_at(i + 1));
             if (rc) return rc;
             ++i;
             continue;
@@ -357,15 +368,16 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         if (rc) return rc;
     }
     // keep the host mirror of `seen` exact, or drop it
-    if (!known) h->host_seen_valid = false;
-    else if (host_ids && h->host_seen_valid) {
-        for (int i = 0; i < m; ++i) {
-            const int id = host_ids[i];
-            if (id < 0) continue;                                       // skipped marker
-            if (id < 1 || id > h->n || id > total) { h->host_seen_valid = false; break; }   // error / break paths: stop mirroring
-            if (id > h->host_seen) h->host_seen = id;
-        }
-    } else if (!host_ids) h->host_seen_valid = false;
+    if (!known || !have_ids) h->host_seen_valid = false;
+    else if (h->host_seen_valid && !plain) {                            // plain ticks leave `seen` where it was
+        for (int b = 0; b < h->B && h->host_seen_valid; ++b)
+            for (int i = 0; i < m; ++i) {
+                const int id = id_of(b, i);
+                if (id < 0) continue;                                   // skipped marker
+                if (id < 1 || id > h->n || id > total) { h->host_seen_valid = false; break; }   // error / break paths: stop mirroring
+                if (id > h->host_seen[b]) h->host_seen[b] = id;
+            }
+    }
     return NUSLAM_OK;
 }
 
@@ -375,7 +387,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -452,7 +464,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     if (rc) return rc;
     HIPCHK(e);
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
-    h->host_seen = 0; h->host_seen_valid = true;
+    h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
     return NUSLAM_OK;
 }
 
@@ -534,8 +546,8 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
-    if (h->B == 1) { h->host_seen = seen; h->host_seen_valid = true; }
-    else h->host_seen_valid = false;
+    if (h->B == 1) { h->host_seen[0] = seen; h->host_seen_valid = true; }
+    else if (h->host_seen_valid) h->host_seen[b] = seen;
     return NUSLAM_OK;
 }
 
@@ -607,6 +619,22 @@ int nuslam_cartesian2polar(double x, double y, double out[2])
     return NUSLAM_OK;
 }
 
+// EKFSlam::broadcast_map2odom_tf, slam.cpp:175-210, on the host (Transform2D algebra of rigid2d.cpp:170-209)
+int nuslam_map_to_odom(const double odom[3], const double state[3], double out[3])
+{
+    if (!odom || !state || !out) return NUSLAM_E_ARG;
+    const double cob = std::cos(odom[2]), sob = std::sin(odom[2]);                 // T_ob, :179-182
+    const double cmb = std::cos(state[0]), smb = std::sin(state[0]);               // T_mb, :186-188
+    const double ci = cob, si = -sob;                                              // T_ob.inv(), rigid2d.cpp:187-196
+    const double xi = (-odom[0] * cob) + (-odom[1] * sob);
+    const double yi = (odom[0] * sob) + (-odom[1] * cob);
+    const double m10 = (smb * ci) + (cmb * si);                                    // T_mb * T_bo, rigid2d.cpp:198-209
+    out[0] = (cmb * xi) - (smb * yi) + state[1];
+    out[1] = (smb * xi) + (cmb * yi) + state[2];
+    out[2] = h_normalize_angle(std::asin(m10));                                    // :194
+    return NUSLAM_OK;
+}
+
 int nuslam_measurement(const double* s, int len, int j, double out[2])
 {
     if (!s || !out) return NUSLAM_E_ARG;
@@ -661,16 +689,120 @@ int nuslam_batch_size(const nuslam_batch_t* h, int* n_filters, int* len)
     return NUSLAM_OK;
 }
 
+namespace {
+
+void free_trace(nuslam_batch* h)
+{
+    void* olds[] = { h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth };
+    for (void* p : olds)
+        if (p) (void)hipFree(p);
+    h->tr_tw = h->tr_mx = h->tr_my = h->tr_truth = nullptr; h->tr_ids = nullptr;
+    h->tr_ticks = h->tr_m = h->tr_bcast = 0;
+    h->h_ids.clear();
+    h->h_ids_pf.clear();
+}
+
+__global__ void k_philox_probe(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                               unsigned* out)
+{
+    unsigned r[4];
+    philox4x32_10(c0, c1, c2, c3, k0, k1, r);
+    for (int q = 0; q < 4; ++q) out[q] = r[q];
+}
+
+} // namespace
+
+int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4], int device)
+{
+    if (!ctr || !key || !out) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    unsigned* d = nullptr;
+    HIPCHK(hipMalloc(&d, 4 * sizeof(unsigned)));
+    hipLaunchKernelGGL(k_philox_probe, dim3(1), dim3(1), 0, 0, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d, 4 * sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
+                          const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
+                          int known_ids, long long* empty_slots)
+{
+    if (!h || !p || !landmarks || !cmd || n_world < 1 || n_world > kSimMaxWorld || ticks < 1 || m < 1)
+        return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_trace(h);
+    const size_t B = (size_t)h->B, T = (size_t)ticks, M = (size_t)m;
+    double* d_lm = nullptr; double* d_cmd = nullptr; unsigned long long* d_empty = nullptr;
+    HIPCHK(hipMalloc(&h->tr_tw, sizeof(double) * B * T * 2));
+    HIPCHK(hipMalloc(&h->tr_mx, sizeof(double) * B * T * M));
+    HIPCHK(hipMalloc(&h->tr_my, sizeof(double) * B * T * M));
+    HIPCHK(hipMalloc(&h->tr_ids, sizeof(int) * B * T * M));
+    HIPCHK(hipMalloc(&h->tr_truth, sizeof(double) * B * T * 3));
+    HIPCHK(hipMalloc(&d_lm, sizeof(double) * 2 * n_world));
+    HIPCHK(hipMalloc(&d_cmd, sizeof(double) * 2 * T));
+    HIPCHK(hipMalloc(&d_empty, sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(d_lm, landmarks, sizeof(double) * 2 * n_world, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_cmd, cmd, sizeof(double) * 2 * T, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d_empty, 0, sizeof(unsigned long long)));
+    SimArg a;
+    a.p = *p; a.lm = d_lm; a.cmd = d_cmd; a.n_world = n_world; a.ticks = ticks; a.m = m; a.B = h->B;
+    a.seed = seed; a.first_filter = first_filter;
+    a.tw = h->tr_tw; a.mx = h->tr_mx; a.my = h->tr_my; a.ids = h->tr_ids; a.truth = h->tr_truth;
+    a.empty = d_empty; a.raw = nullptr;
+    hipLaunchKernelGGL(k_sim_path, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    const size_t lds = (size_t)n_world * 9;
+    if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sim_markers),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sim_markers, dim3(ticks, h->B), dim3(256), lds, h->stream, a);
+    HIPCHK(hipGetLastError());
+    unsigned long long empty = 0;
+    HIPCHK(hipMemcpyAsync(&empty, d_empty, sizeof(empty), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    (void)hipFree(d_lm); (void)hipFree(d_cmd); (void)hipFree(d_empty);
+    if (empty_slots) *empty_slots = (long long)empty;
+    h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = 0;
+    if (!known_ids) {
+        // data association reads no ids: an unused slot would be taken for a marker at the robot's own position
+        (void)hipFree(h->tr_ids);
+        h->tr_ids = nullptr;
+        if (empty) { free_trace(h); return NUSLAM_E_ARG; }
+    } else {
+        // the host keeps the ids only to decide, tick by tick, whether every correction is a plain one (pairing)
+        std::vector<int>& dst = h->B == 1 ? h->h_ids : h->h_ids_pf;
+        dst.resize(B * T * M);
+        HIPCHK(hipMemcpy(dst.data(), h->tr_ids, sizeof(int) * B * T * M, hipMemcpyDeviceToHost));
+    }
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_get_trace(nuslam_batch_t* h, int b, double* tw, double* mx, double* my, int* ids, double* truth)
+{
+    if (!h || !h->tr_tw || b < 0 || b >= h->B) return NUSLAM_E_ARG;
+    if ((ids && !h->tr_ids) || (truth && !h->tr_truth)) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t bb = h->tr_bcast ? 0 : (size_t)b, T = (size_t)h->tr_ticks, M = (size_t)h->tr_m;
+    if (tw) HIPCHK(hipMemcpy(tw, h->tr_tw + bb * T * 2, sizeof(double) * T * 2, hipMemcpyDeviceToHost));
+    if (mx && M) HIPCHK(hipMemcpy(mx, h->tr_mx + bb * T * M, sizeof(double) * T * M, hipMemcpyDeviceToHost));
+    if (my && M) HIPCHK(hipMemcpy(my, h->tr_my + bb * T * M, sizeof(double) * T * M, hipMemcpyDeviceToHost));
+    if (ids && M) HIPCHK(hipMemcpy(ids, h->tr_ids + bb * T * M, sizeof(int) * T * M, hipMemcpyDeviceToHost));
+    if (truth) HIPCHK(hipMemcpy(truth, h->tr_truth + bb * T * 3, sizeof(double) * T * 3, hipMemcpyDeviceToHost));
+    return NUSLAM_OK;
+}
+
 int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* tw, const double* mx, const double* my,
                             const int* ids, int bcast)
 {
     if (!h || ticks < 1 || m < 0 || !tw || (m > 0 && (!mx || !my))) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    void* olds[] = { h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids };
-    for (void* p : olds)
-        if (p) (void)hipFree(p);
-    h->tr_tw = h->tr_mx = h->tr_my = nullptr; h->tr_ids = nullptr;
+    free_trace(h);
     const size_t nb = bcast ? 1 : (size_t)h->B;
     const size_t mm = m > 0 ? (size_t)m : 1;
     HIPCHK(hipMalloc(&h->tr_tw, sizeof(double) * nb * ticks * 2));
@@ -688,6 +820,7 @@ int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* t
     h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = bcast ? 1 : 0;
     h->h_ids.clear();
     if (ids && m > 0 && (bcast || h->B == 1)) h->h_ids.assign(ids, ids + (size_t)ticks * m);
+    else if (ids && m > 0) h->h_ids_pf.assign(ids, ids + (size_t)h->B * ticks * m);
     return NUSLAM_OK;
 }
 
@@ -708,7 +841,9 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.off = (long long)t * h->tr_m;
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
         const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
-        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks, hid);
+        const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m;
+        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks, hid, nullptr, nullptr, pfid,
+                     (long long)h->tr_ticks * h->tr_m);
     }
     h->id_log = saved_log;
     return rc;

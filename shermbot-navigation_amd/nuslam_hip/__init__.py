@@ -69,7 +69,39 @@ SYMBOLS = [
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
     ("nuslam_batch_timer_start", C.c_int, [_vp]),
     ("nuslam_batch_timer_stop", C.c_int, [_vp, _dp]),
+    ("nuslam_map_to_odom", C.c_int, [_dp, _dp, _dp]),
+    ("nuslam_batch_simulate", C.c_int, [_vp, C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_ulonglong, C.c_uint,
+                                        C.c_int, C.POINTER(C.c_longlong)]),
+    ("nuslam_batch_get_trace", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip, _dp]),
+    ("nuslam_philox4x32_10", C.c_int, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
 ]
+
+
+class SimParams(C.Structure):
+    """nuslam_sim_params (include/nuslam_hip.h).  Defaults: nuturtlesim/config/tube_world_params.yaml and
+    nuturtle_description/config/diff_params.yaml of the reference."""
+    _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
+                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range")]
+
+    def __init__(self, **kw):
+        d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
+                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0)
+        d.update(kw)
+        super().__init__(**d)
+
+
+def map_to_odom(odom_xyth, state3):
+    """EKFSlam::broadcast_map2odom_tf (slam.cpp:175-210): (x, y, yaw) of the map -> odom transform."""
+    out = np.zeros(3)
+    _chk(lib().nuslam_map_to_odom(_p(np.ascontiguousarray(odom_xyth, dtype=np.float64)),
+                                  _p(np.ascontiguousarray(state3, dtype=np.float64)), _p(out)), "map_to_odom")
+    return out
+
+
+def philox(ctr, key, device=0):
+    c = (C.c_uint * 4)(*[int(x) for x in ctr]); k = (C.c_uint * 2)(*[int(x) for x in key]); o = (C.c_uint * 4)()
+    _chk(lib().nuslam_philox4x32_10(c, k, o, device), "philox")
+    return [int(x) for x in o]
 
 
 class NuslamError(RuntimeError):
@@ -224,6 +256,27 @@ class Batch:
             idp = ids.ctypes.data_as(_ip)
         _chk(lib().nuslam_batch_load_trace(self._h, T, m, _p(tw), _p(mx), _p(my), idp, 1 if bcast else 0),
              "batch_load_trace")
+
+    def simulate(self, params, landmarks, cmd, m, seed, first_filter=0, known_ids=True):
+        """Generate the resident trace on the device (tube_world.cpp:509-533 per filter): returns the number of
+        unused marker slots."""
+        lm = np.ascontiguousarray(landmarks, dtype=np.float64).reshape(-1)
+        cmd = np.ascontiguousarray(cmd, dtype=np.float64).reshape(-1, 2)
+        empty = C.c_longlong()
+        _chk(lib().nuslam_batch_simulate(self._h, C.addressof(params), _p(lm), lm.size // 2, _p(cmd), cmd.shape[0],
+                                         int(m), int(seed), int(first_filter), 1 if known_ids else 0,
+                                         C.byref(empty)), "batch_simulate")
+        self._trace_shape = (cmd.shape[0], int(m), bool(known_ids))
+        return empty.value
+
+    def get_trace(self, b=0):
+        """Filter b's generated trace: dict(tw (T,2), mx, my, ids (T,m), truth (T,3))."""
+        T, m, known = self._trace_shape
+        tw = np.zeros((T, 2)); mx = np.zeros((T, m)); my = np.zeros((T, m)); truth = np.zeros((T, 3))
+        ids = np.zeros((T, m), dtype=np.int32) if known else None
+        _chk(lib().nuslam_batch_get_trace(self._h, b, _p(tw), _p(mx), _p(my),
+                                          ids.ctypes.data_as(_ip) if known else None, _p(truth)), "batch_get_trace")
+        return dict(tw=tw, mx=mx, my=my, ids=ids, truth=truth)
 
     def run(self, t_begin, t_end, total_landmarks=None):
         _chk(lib().nuslam_batch_run(self._h, t_begin, t_end, self.n if total_landmarks is None else total_landmarks),

@@ -29,10 +29,26 @@ def build_oracle(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present). Building the checker is not using it."""
     if force or not os.path.exists(ORACLE_SO) or (
             os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(os.path.join(ORACLE_DIR, f))
-                                              for f in ("nuslam_oracle.c", "circle_fit_oracle.c"))):
+                                              for f in ("nuslam_oracle.c", "nuslam_oracle.h", "circle_fit_oracle.c",
+                                                        "sim_oracle.c"))):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/rigid2d/src") and not os.path.exists(REF_SO):
+    if os.path.isdir("/root/reference/rigid2d/src") and (
+            not os.path.exists(REF_SO)
+            or os.path.getmtime(REF_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "ref_shim.cpp"))):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "ref"], stdout=subprocess.DEVNULL)
+
+
+class SimParams(C.Structure):
+    """orc_sim_params (oracle/nuslam_oracle.h); include/nuslam_hip.h's nuslam_sim_params has the same layout.
+    Defaults: nuturtlesim/config/tube_world_params.yaml + nuturtle_description/config/diff_params.yaml."""
+    _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
+                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range")]
+
+    def __init__(self, **kw):
+        d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
+                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0)
+        d.update(kw)
+        super().__init__(**d)
 
 
 _lib = None
@@ -76,6 +92,17 @@ def lib():
         L.orc_circle_fit.argtypes = [_dp, _dp, C.c_int, _dp, _dp]
         L.orc_classify_cluster.argtypes = [_dp, _dp, C.c_int, _dp]
         L.orc_cluster_points.argtypes = [C.POINTER(C.c_float), C.c_double, C.c_double, _dp, _dp, _ip, _ip]
+        L.orc_tf_make.argtypes = [C.c_double, C.c_double, C.c_double, _dp]
+        L.orc_tf_inv.argtypes = [_dp, _dp]
+        L.orc_tf_mul.argtypes = [_dp, _dp, _dp]
+        L.orc_tf_point.argtypes = [_dp, C.c_double, C.c_double, _dp]
+        L.orc_map_to_odom.argtypes = [_dp, _dp, _dp]
+        _up = C.POINTER(C.c_uint)
+        L.orc_philox4x32_10.argtypes = [_up, _up, _up]
+        L.orc_sim_normal_pair.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint, C.c_uint, C.c_uint, _dp]
+        L.orc_simulate.restype = C.c_longlong
+        L.orc_simulate.argtypes = [C.POINTER(SimParams), _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_ulonglong,
+                                   C.c_uint, _dp, _dp, _dp, _ip, _dp, _dp]
         _lib = L
     return _lib
 
@@ -107,6 +134,40 @@ def cluster_points(ranges, min_range, max_range):
     npts = lib().orc_cluster_points(r.ctypes.data_as(C.POINTER(C.c_float)), min_range, max_range, _p(px), _p(py),
                                     cl.ctypes.data_as(_ip), C.byref(ncl))
     return [(px[:npts][cl[:npts] == k].copy(), py[:npts][cl[:npts] == k].copy()) for k in range(ncl.value)]
+
+
+def philox(ctr, key):
+    c = (C.c_uint * 4)(*[int(x) for x in ctr]); k = (C.c_uint * 2)(*[int(x) for x in key]); o = (C.c_uint * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(x) for x in o]
+
+
+def sim_normal_pair(seed, filt, tick, stream, idx):
+    z = np.zeros(2)
+    lib().orc_sim_normal_pair(int(seed), int(filt), int(tick), int(stream), int(idx), _p(z))
+    return z
+
+
+def simulate(params, landmarks, cmd, m, seed, filt=0):
+    """orc_simulate: dict(tw (T,2), mx, my (T,m), ids (T,m), truth (T,3), joints (T,2), empty)."""
+    lm = np.ascontiguousarray(landmarks, dtype=np.float64).reshape(-1)
+    cmd = np.ascontiguousarray(cmd, dtype=np.float64).reshape(-1, 2)
+    T, n = cmd.shape[0], lm.size // 2
+    mm = max(m, 1)
+    tw = np.zeros((T, 2)); mx = np.zeros((T, mm)); my = np.zeros((T, mm)); ids = np.zeros((T, mm), dtype=np.int32)
+    truth = np.zeros((T, 3)); joints = np.zeros((T, 2))
+    empty = lib().orc_simulate(C.byref(params), _p(lm), n, _p(cmd), T, m, int(seed), int(filt), _p(tw), _p(mx),
+                               _p(my), ids.ctypes.data_as(_ip), _p(truth), _p(joints))
+    if empty < 0:
+        raise OracleError(ORC_E_ARG)
+    return dict(tw=tw, mx=mx[:, :m], my=my[:, :m], ids=ids[:, :m], truth=truth, joints=joints, empty=int(empty))
+
+
+def map_to_odom(odom, state3):
+    out = np.zeros(3)
+    lib().orc_map_to_odom(_p(np.ascontiguousarray(odom, dtype=np.float64)),
+                          _p(np.ascontiguousarray(state3, dtype=np.float64)), _p(out))
+    return out
 
 
 def usable_cpus():
@@ -327,5 +388,9 @@ def ref():
         R.ref_dd_convert_twist.argtypes = [_dp, _dp, _dp]
         R.ref_dd_get_twist.argtypes = [_dp, C.c_double, C.c_double, _dp]
         R.ref_dd_step.argtypes = [_dp, C.c_double, C.c_double]
+        R.ref_tf_inv.argtypes = [C.c_double] * 3 + [_dp]
+        R.ref_tf_mul.argtypes = [C.c_double] * 6 + [_dp]
+        R.ref_tf_point.argtypes = [C.c_double] * 5 + [_dp]
+        R.ref_map_to_odom.argtypes = [_dp, _dp, _dp]
         _ref = R
     return _ref

@@ -4,6 +4,7 @@
   rigid2d_ref.npz   inputs + outputs of the REFERENCE's own rigid2d / DiffDrive code (oracle/_ref/librigid2d_ref.so,
                     compiled from /root/reference/rigid2d/src/{rigid2d,diff_drive}.cpp by oracle/Makefile).  These
                     are reference-generated golden vectors: they pin the oracle's rigid2d part and the host C++ mirror.
+  tf_ref.npz        the same for Transform2D inverse / product / point map and the map->odom algebra of slam.cpp:175-210.
   ekf_oracle.npz    traces + per-tick outputs of the ORACLE (oracle/nuslam_oracle.c, dense mode) for the EKF part.
                     The reference's EKF translation unit cannot be built here (needs Armadillo) and the reference
                     has no EKF test or recorded trace, so these are regression fixtures of the restatement, NOT
@@ -69,6 +70,27 @@ def rigid2d_ref():
              dd0=dd0, wheel=wheel, dd_traj=dd_traj, dd_tw=dd_tw, conv_tw=conv_tw, conv=conv)
 
 
+def tf_ref():
+    """Transform2D inverse / product / point map and the slam node's map->odom algebra (slam.cpp:175-210), computed by
+    the reference's own Transform2D (oracle/_ref).  Kept in its own file so the older fixtures stay byte-stable."""
+    assert O.ref_available()
+    R = O.ref()
+    rng = np.random.default_rng(20261005)
+    K = 48
+    a = rng.normal(size=(K, 3)) * np.array([2.0, 2.0, 3.0])      # x, y, rad
+    b = rng.normal(size=(K, 3)) * np.array([2.0, 2.0, 3.0])
+    a[:4, 2] = 0.0; b[4:8, 2] = 0.0
+    pt = rng.normal(size=(K, 2))
+    inv = np.zeros((K, 4)); mul = np.zeros((K, 4)); point = np.zeros((K, 2)); m2o = np.zeros((K, 3))
+    for i in range(K):
+        R.ref_tf_inv(a[i, 0], a[i, 1], a[i, 2], p(inv[i]))
+        R.ref_tf_mul(a[i, 0], a[i, 1], a[i, 2], b[i, 0], b[i, 1], b[i, 2], p(mul[i]))
+        R.ref_tf_point(a[i, 0], a[i, 1], a[i, 2], pt[i, 0], pt[i, 1], p(point[i]))
+        # odom = (x, y, th); filter pose = (th, x, y)
+        R.ref_map_to_odom(p(np.ascontiguousarray(a[i])), p(np.ascontiguousarray(b[i, [2, 0, 1]])), p(m2o[i]))
+    np.savez(os.path.join(HERE, "tf_ref.npz"), a=a, b=b, pt=pt, inv=inv, mul=mul, point=point, m2o=m2o)
+
+
 def ekf_oracle():
     Q, Rn = synth.Q_DEFAULT, synth.R_DEFAULT
     out = {}
@@ -122,6 +144,10 @@ def ekf_oracle():
 
 
 if __name__ == "__main__":
+    if "--tf-only" in sys.argv:
+        tf_ref()
+        sys.exit(0)
     rigid2d_ref()
+    tf_ref()
     ekf_oracle()
     print("wrote", os.listdir(HERE))

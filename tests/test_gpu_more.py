@@ -170,8 +170,13 @@ def test_cpp_host_mirror_replays_slam_loop(hip):
     dd = O.dd_new(synth.WHEEL_BASE, synth.WHEEL_RADIUS)
     rows = [l.split() for l in out.stdout.splitlines()]
     trows = [r for r in rows if r[0] == "T"]
+    mrows = [r for r in rows if r[0] == "M"]
     for t in range(T):
         ids = o.tick(dd=dd, thL=tr.thL[t], thR=tr.thR[t], mx=tr.mx[t], my=tr.my[t])
+        # map -> odom (slam.cpp:175-210): the host DiffDrive is bit-equal to the oracle's, so from the printed pose
+        # estimate the oracle's algebra must give the printed transform
+        want = O.map_to_odom(dd[[2, 3, 4]], [float(x) for x in trows[t][2:5]])
+        assert np.allclose([float(x) for x in mrows[t][1:4]], want, atol=1e-14, rtol=0)
         assert np.array_equal(ids, g["da_ids"][t])
         assert int(trows[t][1]) == o.seen
         assert np.allclose([float(x) for x in trows[t][2:5]], o.state[:3], atol=1e-4, rtol=0)

@@ -157,3 +157,50 @@ def test_pair_batch_and_full_size(hip):
             g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
         out.append((g.state, g.cov))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_pair_with_per_filter_ids_in_resident_trace(hip):
+    """B Monte-Carlo filters, each replaying its OWN trace (different landmark ids per filter): once every filter's
+    map is initialised the host pairs the corrections, the kernel reads each filter's ids from the resident trace,
+    and the result is bit for bit what single launches give.  While some filter still has a landmark to initialise
+    (the cold first ticks) the host must not pair."""
+    B, n, m, T = 3, 20, 6, 8
+    lm = synth.make_landmarks(n)
+    traces = [synth.make_trace(n, T, m, seed=100 + b, landmarks=lm) for b in range(B)]
+    for b in range(B):                                   # make the id patterns differ between the filters
+        traces[b].ids[:] = np.roll(traces[b].ids, b, axis=1)
+        traces[b].mx[:] = np.roll(traces[b].mx, b, axis=1); traces[b].my[:] = np.roll(traces[b].my, b, axis=1)
+    tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces]); my = np.stack([t.my for t in traces])
+    ids = np.stack([t.ids for t in traces])
+    assert not np.array_equal(ids[0], ids[1])
+    bx, by, wid = synth.warmup_observations(lm)
+    res = []
+    for pairing in (True, False):
+        bt = hip.Batch(B, n, Q, R)
+        bt.set_pairing(pairing)
+        bt.load_trace(tw, mx, my, ids)
+        bt.profile(True)
+        bt.run(0, 1)                                     # cold: landmarks get initialised, never paired
+        bt.sync()
+        assert bt.profile_read(hip.K_UPDATE2)[1] == 0 and bt.profile_read(hip.K_UPDATE)[1] == m
+        bt.run(1, 3)
+        bt.profile(False)
+        # finish initialising every landmark in every filter, then replay the rest of the per-filter traces
+        bt2 = hip.Batch(B, n, Q, R)
+        bt2.set_pairing(pairing)
+        bt2.load_trace(np.zeros((1, 2)), bx[None], by[None], wid[None], bcast=True)
+        bt2.run(0, 1)
+        bt2.load_trace(tw, mx, my, ids)
+        bt2.profile(True)
+        bt2.run(0, T)
+        bt2.sync()
+        n2, n1 = bt2.profile_read(hip.K_UPDATE2)[1], bt2.profile_read(hip.K_UPDATE)[1]
+        assert (n2, n1) == ((T * m // 2, 0) if pairing else (0, T * m))
+        bt2.profile(False)
+        res.append([(bt2.state(b), bt2.cov(b), bt2.seen(b)) for b in range(B)] +
+                   [(bt.state(b), bt.cov(b), bt.seen(b)) for b in range(B)])
+        assert bt2.status()[1] == 0
+    for (s1, c1, k1), (s2, c2, k2) in zip(*res):
+        assert np.array_equal(s1, s2) and np.array_equal(c1, c2) and k1 == k2
+    # and the filters really are different trials
+    assert not np.array_equal(res[0][0][0], res[0][1][0])
