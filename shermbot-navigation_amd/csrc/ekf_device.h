@@ -83,6 +83,25 @@ __device__ inline void cartesian2polar(double x, double y, double& r, double& b)
     b = normalize_angle(atan2(y, x));
 }
 
+// The raw marker of filter `bidx`, loaded UNCONDITIONALLY (the address falls back to `safe`, any readable double,
+// when the marker travels inline): a kernel that wants the value while its tile loads are still in flight must issue
+// this load before them in straight-line code -- vmcnt retires in order, and a load inside a branch makes the
+// compiler's scoreboard merge conservative (s_waitcnt vmcnt(0)).
+__device__ inline void load_obs_raw(const double* oa, const double* ob, long long stride, long long off, double a0,
+                                    double b0, int bidx, const double* safe, double& a, double& b)
+{
+    const double* pa = oa ? oa + (bidx * stride + off) : safe;
+    const double* pb = ob ? ob + (bidx * stride + off) : safe;
+    const double la = *pa, lb = *pb;
+    a = oa ? la : a0;
+    b = ob ? lb : b0;
+}
+__device__ inline void obs_polar(const ObsArg& o, double a, double b, double& r, double& phi)
+{
+    if (o.cartesian) cartesian2polar(a, b, r, phi);        // slam.cpp:286
+    else { r = a; phi = b; }
+}
+
 __device__ inline void fetch_obs(const ObsArg& o, int bidx, double& r, double& phi)
 {
     double a = o.a ? o.a[bidx * o.stride + o.off] : o.a0;

@@ -857,6 +857,27 @@ int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const do
     return restore(h, b, state, cov, ld, seen);
 }
 
+#ifdef NUSLAM_PHASE_CLOCK
+extern "C" int nuslam_debug_phase(long long out[32])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_phase), sizeof(long long) * 32));
+    return NUSLAM_OK;
+}
+extern "C" int nuslam_debug_hwid(unsigned* out, int n_wg)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_hwid), sizeof(unsigned) * 8 * n_wg));
+    return NUSLAM_OK;
+}
+extern "C" int nuslam_debug_wg(long long* out, int n_wg)
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_wg), sizeof(long long) * 2 * n_wg));
+    return NUSLAM_OK;
+}
+#endif
+
 int nuslam_batch_sync(nuslam_batch_t* h)
 {
     if (!h) return NUSLAM_E_ARG;
