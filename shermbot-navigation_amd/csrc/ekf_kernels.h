@@ -25,6 +25,29 @@ namespace nuslam {
 // 16 bytes of consecutive rows of one column: what one lane moves per global_load/store_dwordx4
 template <typename T> struct alignas(16) Pack16 { T v[16 / sizeof(T)]; };
 
+// 16-byte streaming store (global_store_dwordx4 ... nt): the written tile is not read again by this kernel, and the
+// next kernel's readers sit on other XCDs (other L2s), so the lines have no business staying dirty in this L2 until
+// the end-of-kernel write-back.
+template <typename T>
+__device__ inline Pack16<T> load_stream(const T* p)
+{
+    typedef T vt __attribute__((ext_vector_type(16 / sizeof(T))));
+    const vt y = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+    Pack16<T> x;
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); ++e) x.v[e] = y[e];
+    return x;
+}
+template <typename T>
+__device__ inline void store_stream(T* p, const Pack16<T>& x)
+{
+    typedef T vt __attribute__((ext_vector_type(16 / sizeof(T))));
+    vt y;
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); ++e) y[e] = x.v[e];
+    __builtin_nontemporal_store(y, reinterpret_cast<vt*>(p));
+}
+
 constexpr int kStatusBounds = 2;    // NUSLAM_E_BOUNDS
 constexpr int kStatusSingular = 3;  // NUSLAM_E_SINGULAR
 

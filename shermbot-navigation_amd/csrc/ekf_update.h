@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     const T* Pr = Pb + (size_t)j0 * ld + rowc;
     vec_t p[CW];
 #pragma unroll
-    for (int jj = 0; jj < CW; ++jj) p[jj] = *reinterpret_cast<const vec_t*>(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);   // read once: streaming
     vec_t pc[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
             acc = fma(after[e], pij, acc);
             out.v[e] = (T)acc;
         }
-        if (jj < ncol && rows_ok) *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = out;
+        if (jj < ncol && rows_ok) store_stream(Pw + (size_t)jj * ld, out);     // written once, read next by other XCDs
     }
 }
 

@@ -68,17 +68,27 @@ __device__ inline double p1_entry(const double m[5], const double r[5], double p
 // mid-grid workgroup stamps the 100 MHz wall clock at each phase boundary.  Compiled out of the product.
 #ifdef NUSLAM_PHASE_CLOCK
 __device__ long long g_phase[32];
-__device__ unsigned g_hwid[4096][4][2];      // HW_ID and XCC_ID of every wave
+__device__ unsigned g_hwid[4096][8][2];      // HW_ID and XCC_ID of every wave
 __device__ long long g_wg[4096][2];          // entry / exit stamp of every workgroup (wave 0), index = y * gridDim.x + x
 #define PHASE(k)                                                                                        \
     do {                                                                                                \
-        if (blockIdx.x == 3 && (blockIdx.y == 10 || blockIdx.y == 26) && blockIdx.z == 0 && (threadIdx.x & 63) == 0 && \
+        if (blockIdx.x == 3 && (blockIdx.y == 40 / NUSLAM_K2_WAVES || blockIdx.y == 104 / NUSLAM_K2_WAVES) &&   \
+            blockIdx.z == 0 && (threadIdx.x & 63) == 0 &&                                                      \
             (threadIdx.x >> 6) == 0)                                                                            \
-            g_phase[(blockIdx.y == 26 ? 16 : 0) + k] = (long long)wall_clock64();                       \
+            g_phase[(blockIdx.y == 104 / NUSLAM_K2_WAVES ? 16 : 0) + k] = (long long)wall_clock64();                       \
     } while (0)
 #else
 #define PHASE(k) do { } while (0)
 #endif
+
+// Waves per workgroup.  Every workgroup recomputes the two heads (a ~4 us serial chain of wave64 fp64 instructions);
+// a CU holds 8 of these waves.  As two 4-wave workgroups the CU runs two chains, and the later-dispatched workgroup
+// (its waves lose instruction arbitration to the older one's sweep) finishes 4 us after the first; as ONE 8-wave
+// workgroup the CU runs one chain and all eight tiles are swept together.
+#ifndef NUSLAM_K2_WAVES
+#define NUSLAM_K2_WAVES 8
+#endif
+constexpr int kPairWaves = NUSLAM_K2_WAVES;
 
 // LDS layout (doubles)
 enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 5x5: M1(set2[a], set1[q]) */,
@@ -87,7 +97,7 @@ enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 
        S2_NU2 = 102 /* z2 - z_hat2 */, S2_WORDS = 104 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
+__global__ __launch_bounds__(64 * kPairWaves, 8 / kPairWaves) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
                                                  T* __restrict__ Pout)
 {
     constexpr int CW = 16;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
 #ifdef NUSLAM_FLIP_Y
     const int strip = (gridDim.y - 1 - blockIdx.y) * 4 + wave;       // experiment: which half is slow, the data's or the dispatch's?
 #else
-    const int strip = blockIdx.y * 4 + wave;
+    const int strip = blockIdx.y * kPairWaves + wave;
 #endif
     // Which wave carries which phase-A/B role rotates with the workgroup's dispatch generation.  Wave k of every
     // workgroup lands on SIMD k, the head chain is ~3000 wave64 fp64 instructions at 4 cycles each whatever the EXEC
@@ -187,7 +197,9 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
     const T* Pr = Pb + (size_t)j0 * ld + rowc;
     vec_t p[CW];
 #pragma unroll
-    for (int jj = 0; jj < CW; ++jj) p[jj] = *reinterpret_cast<const vec_t*>(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+    // streaming: every tile element is read once and written once (the strips and gain columns, which are shared
+    // between workgroups, stay ordinary cached loads)
+    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
     PHASE(12);
 
     // ---- phase A, four roles in parallel (the transcendental chains need the state and the trace only, not P):
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
         measurement(lane_bcast(v_st, 0), lane_bcast(v_st, 1), lane_bcast(v_st, 2), lane_bcast(v_st, 3),
                     lane_bcast(v_st, 4), zr, zb);
         if (lane == 0) { sh[S2_DZ1] = zr; sh[S2_DZ1 + 1] = zb; }
-    } else {
+    } else if (role == 0) {
         const double x = lane_bcast(v_st, 1), y = lane_bcast(v_st, 2);
         const double l1x = lane_bcast(v_st, 3), l1y = lane_bcast(v_st, 4);
         status = status_in;
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
     // ---- the sweep: both corrections on the tile in registers.  The ten prior-row values of a column (R1, R2) are
     // wave-uniform; they go through a per-wave LDS strip and come back as broadcast ds_read_b128 -- 5 LDS reads per
     // column instead of 20 v_readlane, which were a sixth of this kernel's VALU instructions.
-    __shared__ double sR[4][CW][10];
+    __shared__ double sR[kPairWaves][CW][10];
     {
         double(*R)[10] = sR[wave];
         R[sj][sq] = vA;                               // r1[0..3] = rows 0, 1, 2, c1
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_update2(View v, ObsArg o1, ObsArg o2
             const double p1 = p1_entry<T>(m1[e], r1v, (double)p[jj].v[e], bef1[e], aft1[e]);
             out.v[e] = (T)sweep_entry(m2[e], r2v, p1, bef2[e], aft2[e]);
         }
-        if (jj < ncol && rows_ok) *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = out;
+        if (jj < ncol && rows_ok) store_stream(Pw + (size_t)jj * ld, out);
     }
 #ifdef NUSLAM_PHASE_CLOCK
     PHASE(9);

@@ -280,7 +280,7 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
     View v = h->view();
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + kPairWaves - 1) / kPairWaves, h->B), block(64 * kPairWaves);
     int rc = NUSLAM_OK;
     DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
     if (rc) return rc;
@@ -867,7 +867,7 @@ extern "C" int nuslam_debug_phase(long long out[32])
 extern "C" int nuslam_debug_hwid(unsigned* out, int n_wg)
 {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_hwid), sizeof(unsigned) * 8 * n_wg));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_hwid), sizeof(unsigned) * 16 * n_wg));
     return NUSLAM_OK;
 }
 extern "C" int nuslam_debug_wg(long long* out, int n_wg)

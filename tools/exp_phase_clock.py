@@ -35,7 +35,8 @@ def main():
     ekf.sync()
     rows = []
     L.nuslam_debug_wg.argtypes = [C.POINTER(C.c_longlong), C.c_int]
-    gx, gy = (nh_ld(n) + 127) // 128, ((3 + 2 * n + 15) // 16 + 3) // 4
+    W = int(os.environ.get('K2_WAVES', 8))
+    gx, gy = (nh_ld(n) + 127) // 128, ((3 + 2 * n + 15) // 16 + W - 1) // W
     spans, resid, exits = [], [], []
     for t in range(60):
         # one pair at a time so that the stamps belong to a known launch
@@ -65,12 +66,12 @@ def main():
     lin = np.arange(gx * gy).reshape(gy, gx)
     print("median exit by XCD (linear id % 8):", [round(float(np.median(ext[lin % 8 == k])), 2) for k in range(8)])
     L.nuslam_debug_hwid.argtypes = [C.POINTER(C.c_uint), C.c_int]
-    hw = (C.c_uint * (8 * gx * gy))()
+    hw = (C.c_uint * (16 * gx * gy))()
     L.nuslam_debug_hwid(hw, gx * gy)
-    hw = np.array(hw[:], dtype=np.uint32).reshape(gy * gx, 4, 2)
+    hw = np.array(hw[:], dtype=np.uint32).reshape(gy * gx, 8, 2)[:, :W]
     print("placement of the last launch: workgroup -> (xcc, se, cu) and the SIMD of each of its four waves")
     place = {}
-    for wg in list(range(0, 6)) + list(range(256, 262)):
+    for wg in list(range(0, 4)) + list(range(gx * gy // 2, gx * gy // 2 + 4)):
         ids = hw[wg, :, 0]
         print("  wg %3d: xcc %s se %s cu %s simd %s wave-slot %s" % (wg, hw[wg, :, 1] & 0xf, (ids >> 13) & 7, (ids >> 8) & 15,
                                                                    (ids >> 4) & 3, ids & 15))
