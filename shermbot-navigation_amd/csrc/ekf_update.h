@@ -86,8 +86,14 @@ __device__ inline double lane_bcast(double val, int src)
 // scalar loads.  With the landmark id passed inline every address depends only on kernel arguments.
 // MODE and INLINE_ID are compile-time so that the known-association fast path (id inside the kernel arguments)
 // contains no load at all in front of the burst.
+// Waves per workgroup: one head chain per CU (see the note at kPairWaves in ekf_update2.h)
+#ifndef NUSLAM_K1_WAVES
+#define NUSLAM_K1_WAVES 8
+#endif
+constexpr int kSweepWaves = NUSLAM_K1_WAVES;
+
 template <typename T, int CW, int MODE, bool INLINE_ID>
-__global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_landmarks,
+__global__ __launch_bounds__(64 * kSweepWaves) void k_update(View v, ObsArg o, int total_landmarks,
                                                 const T* __restrict__ Pin, T* __restrict__ Pout)
 {
     constexpr int mode = MODE;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ld = v.ld, L = v.L;
     const int row0 = (blockIdx.x * 64 + lane) * VEC;
-    const int strip = blockIdx.y * 4 + wave;
+    const int strip = blockIdx.y * kSweepWaves + wave;
     const bool active = strip * CW < L;                   // wave-uniform; idle waves only keep the barrier company
     const int j0 = active ? strip * CW : 0;
     const bool rows_ok = row0 < ld;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     const int ncol = (L - j0) < CW ? (L - j0) : CW;       // wave-uniform
 
     // what wave 0 of the workgroup computes once for all four waves: Hc[10], Sinv[4], lx, ly, th, x, y
-    __shared__ double sh_d[20];
+    __shared__ double sh_d[24];                           // [20..23]: marker (r, phi) and z_hat of a plain correction
     __shared__ int sh_i[2];                               // skip, latched status
 
     // (1) control words and the landmark column.  cg is always safe to read; it equals the landmark's column
@@ -126,32 +132,43 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     const double* s = v.s_in + (size_t)b * ld;
     const T* Pb = Pin + (size_t)b * v.p_stride;
 
-    // (2) one burst of vector loads
-    //  (a) wave 0 only -- lanes 0..24: the 5x5 block, lane = 5q + q2 holds P(set[q2], set[q]); lanes 32..36: th, x, y, lx, ly
-    double v_blk = 0, v_st = 0;
-    if (wave == 0) {
-        const int bq = lane < 25 ? lane / 5 : 0, bq2 = lane < 25 ? lane % 5 : 0;
-        const int cq = bq < 3 ? bq : cg + (bq - 3), cq2 = bq2 < 3 ? bq2 : cg + (bq2 - 3);
-        v_blk = (double)Pb[(size_t)cq * ld + cq2];
-        const int sl = lane - 32;
-        const int si = (sl >= 0 && sl < 3) ? sl : (sl == 3 ? cg : (sl == 4 ? cg + 1 : 0));
-        v_st = s[si];
+    // (2) one burst of vector loads, in the order they are needed (vmcnt retires in order): first, in straight-line
+    // code, the few values the serial head chain consumes; nothing bulky is requested before they are back (the gate),
+    // because all workgroups are resident at once and the memory system serves requests roughly in arrival order.
+    //  (a) lanes 32..36 of every wave: th, x, y, lx, ly; the head wave's lanes 0..24: the 5x5 block, lane = 5q + q2
+    //      holds P(set[q2], set[q]) (the other waves fetch one element instead: no branch around the load)
+    const bool blk_lane = wave == 0 && lane < 25;
+    const int bq = blk_lane ? lane / 5 : 0, bq2 = blk_lane ? lane % 5 : 0;
+    const int cq = bq < 3 ? bq : cg + (bq - 3), cq2 = bq2 < 3 ? bq2 : cg + (bq2 - 3);
+    const double v_blk = (double)Pb[(size_t)cq * ld + cq2];
+    const int sl = lane - 32;
+    const int si = (sl >= 0 && sl < 3) ? sl : (sl == 3 ? cg : (sl == 4 ? cg + 1 : 0));
+    const double v_st = s[si];
+    double raw_a, raw_b;                                  // the marker as it travels (x, y or range, bearing)
+    load_obs_raw(o.a, o.b, o.stride, o.off, o.a0, o.b0, b, s, raw_a, raw_b);
+    //      this lane's state rows (fp64 storage only; the fp32 variant has four rows per lane and no registers to spare)
+    constexpr bool kEarlyRows = (VEC == 2);
+    double s_rows[VEC];
+    if (kEarlyRows) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s_rows[e] = s[rowc + e];
     }
+    __builtin_amdgcn_s_waitcnt(0x0070);                   // the gate: vmcnt(0)
     //  (b) the prior rows of this wave's columns: lane = 16q + jj holds P(set[q], j0 + jj), q < 3 in vA, q - 3 < 2 in vB
     const int sj = lane & 15, sq = lane >> 4;
     const int sjc = sj < ncol ? sj : 0;
     const T* colp = Pb + (size_t)(j0 + sjc) * ld;
     const double vA = (double)colp[sq < 3 ? sq : 0];
     const double vB = (double)colp[cg + (sq & 1)];
-    //  (c) the tile: CW independent 16-byte loads per lane, then the five gain columns
-    const T* Pr = Pb + (size_t)j0 * ld + rowc;
-    vec_t p[CW];
-#pragma unroll
-    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);   // read once: streaming
+    //  (c) the five gain columns, then the tile: CW independent 16-byte loads per lane
     vec_t pc[5];
 #pragma unroll
     for (int q = 0; q < 5; ++q)
         pc[q] = *reinterpret_cast<const vec_t*>(Pb + (size_t)(q < 3 ? q : cg + (q - 3)) * ld + rowc);
+    const T* Pr = Pb + (size_t)j0 * ld + rowc;
+    vec_t p[CW];
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);   // read once: streaming
 
     // (3) decision (every wave: a few scalar compares) + the shared quantities (wave 0, then LDS)
     const Decision d = resolve(v.n, id_raw, seen_now, cached, brk, status_now, mode, total_landmarks);
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
         if (!skip0) {
             if (d.init) {                                 // initializeLandmark, slam_library.cpp:255-261
                 double r, phi;
-                fetch_obs(o, b, r, phi);
+                obs_polar(o, raw_a, raw_b, r, phi);
                 lx0 = x + r * cos(phi + th);
                 ly0 = y + r * sin(phi + th);
             } else { lx0 = lane_bcast(v_st, 35); ly0 = lane_bcast(v_st, 36); }
@@ -191,6 +208,20 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
             sh_d[14] = lx0; sh_d[15] = ly0; sh_d[16] = th; sh_d[17] = x; sh_d[18] = y;
             sh_i[0] = skip0 ? 1 : 0; sh_i[1] = st;
         }
+    } else if (blockIdx.y == 0 && !d.skip && !d.init) {
+        // The innovation z - z_hat (five atan2, sin/cos pairs) only feeds the state correction, which column strip 0's
+        // waves apply.  For a plain correction it needs nothing the head produces, so two otherwise idle waves of
+        // those workgroups form it while the head chain runs (it used to be their tail, after the barrier).
+        if (wave == 1) {
+            double r, phi;
+            obs_polar(o, raw_a, raw_b, r, phi);
+            if (lane == 0) { sh_d[20] = r; sh_d[21] = phi; }
+        } else if (wave == 2) {
+            double zr, zb;                                // :265
+            measurement(lane_bcast(v_st, 32), lane_bcast(v_st, 33), lane_bcast(v_st, 34), lane_bcast(v_st, 35),
+                        lane_bcast(v_st, 36), zr, zb);
+            if (lane == 0) { sh_d[22] = zr; sh_d[23] = zb; }
+        }
     }
     __syncthreads();
     if (!active) return;
@@ -208,8 +239,10 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
     double dz0 = 0, dz1 = 0;
     if (owns_state && !skip) {
         double r, phi, zr, zb;
-        fetch_obs(o, b, r, phi);
-        measurement(sh_d[16], sh_d[17], sh_d[18], lx, ly, zr, zb);   // :265
+        if (d.init) {                                     // z_hat at the landmark the head wave just initialised
+            obs_polar(o, raw_a, raw_b, r, phi);
+            measurement(sh_d[16], sh_d[17], sh_d[18], lx, ly, zr, zb);   // :265
+        } else { r = sh_d[20]; phi = sh_d[21]; zr = sh_d[22]; zb = sh_d[23]; }
         dz0 = r - zr;                                     // :272, bearing innovation not wrapped
         dz1 = phi - zb;
     }
@@ -226,12 +259,12 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
         if (!rows_ok) return;
 #pragma unroll
         for (int jj = 0; jj < CW; ++jj)
-            if (jj < ncol) *reinterpret_cast<vec_t*>(Pw + (size_t)jj * ld) = p[jj];
+            if (jj < ncol) store_stream(Pw + (size_t)jj * ld, p[jj]);
         if (owns_state) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int i = row0 + e;
-                double sv = s[i];
+                double sv = kEarlyRows ? s_rows[e] : s[i];
                 if (d.init && i == c) sv = lx;            // the landmark was initialised before update() threw
                 if (d.init && i == c + 1) sv = ly;
                 so[i] = sv;
@@ -276,7 +309,7 @@ __global__ __launch_bounds__(256) void k_update(View v, ObsArg o, int total_land
             double acc = 0.0;
             acc = fma(K[0], dz0, acc);
             acc = fma(K[1], dz1, acc);
-            double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : s[i];
+            double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : (kEarlyRows ? s_rows[e] : s[i]);
             sv = sv + acc;
             if (i == 0) sv = normalize_angle(sv);
             so[i] = sv;

@@ -257,7 +257,7 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     View v = h->view();
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + kSweepWaves - 1) / kSweepWaves, h->B), block(64 * kSweepWaves);
     int rc = NUSLAM_OK;
     const bool inl = (o.ids == nullptr);
 #define LAUNCH_UPDATE(MODE_, INL_)                                                                              \
