@@ -32,7 +32,11 @@ template <typename T>
 __device__ inline Pack16<T> load_stream(const T* p)
 {
     typedef T vt __attribute__((ext_vector_type(16 / sizeof(T))));
+#ifdef NUSLAM_NO_STREAM
+    const vt y = *reinterpret_cast<const vt*>(p);
+#else
     const vt y = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
+#endif
     Pack16<T> x;
 #pragma unroll
     for (int e = 0; e < (int)(16 / sizeof(T)); ++e) x.v[e] = y[e];
@@ -45,7 +49,11 @@ __device__ inline void store_stream(T* p, const Pack16<T>& x)
     vt y;
 #pragma unroll
     for (int e = 0; e < (int)(16 / sizeof(T)); ++e) y[e] = x.v[e];
+#ifdef NUSLAM_NO_STREAM
+    *reinterpret_cast<vt*>(p) = y;
+#else
     __builtin_nontemporal_store(y, reinterpret_cast<vt*>(p));
+#endif
 }
 
 constexpr int kStatusBounds = 2;    // NUSLAM_E_BOUNDS

@@ -86,14 +86,9 @@ __device__ inline double lane_bcast(double val, int src)
 // scalar loads.  With the landmark id passed inline every address depends only on kernel arguments.
 // MODE and INLINE_ID are compile-time so that the known-association fast path (id inside the kernel arguments)
 // contains no load at all in front of the burst.
-// Waves per workgroup: one head chain per CU (see the note at kPairWaves in ekf_update2.h)
-#ifndef NUSLAM_K1_WAVES
-#define NUSLAM_K1_WAVES 8
-#endif
-constexpr int kSweepWaves = NUSLAM_K1_WAVES;
-
-template <typename T, int CW, int MODE, bool INLINE_ID>
-__global__ __launch_bounds__(64 * kSweepWaves) void k_update(View v, ObsArg o, int total_landmarks,
+// WAVES per workgroup: 8 = one head chain per CU when the grid is one resident generation, else 4 (see ekf_update2.h)
+template <typename T, int CW, int MODE, bool INLINE_ID, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_update(View v, ObsArg o, int total_landmarks,
                                                 const T* __restrict__ Pin, T* __restrict__ Pout)
 {
     constexpr int mode = MODE;
@@ -105,7 +100,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_update(View v, ObsArg o, i
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ld = v.ld, L = v.L;
     const int row0 = (blockIdx.x * 64 + lane) * VEC;
-    const int strip = blockIdx.y * kSweepWaves + wave;
+    const int strip = blockIdx.y * WAVES + wave;
     const bool active = strip * CW < L;                   // wave-uniform; idle waves only keep the barrier company
     const int j0 = active ? strip * CW : 0;
     const bool rows_ok = row0 < ld;

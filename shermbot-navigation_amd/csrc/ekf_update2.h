@@ -72,10 +72,10 @@ __device__ unsigned g_hwid[4096][8][2];      // HW_ID and XCC_ID of every wave
 __device__ long long g_wg[4096][2];          // entry / exit stamp of every workgroup (wave 0), index = y * gridDim.x + x
 #define PHASE(k)                                                                                        \
     do {                                                                                                \
-        if (blockIdx.x == 3 && (blockIdx.y == 40 / NUSLAM_K2_WAVES || blockIdx.y == 104 / NUSLAM_K2_WAVES) &&   \
+        if (blockIdx.x == 3 && (blockIdx.y == 40 / WAVES || blockIdx.y == 104 / WAVES) &&   \
             blockIdx.z == 0 && (threadIdx.x & 63) == 0 &&                                                      \
             (threadIdx.x >> 6) == 0)                                                                            \
-            g_phase[(blockIdx.y == 104 / NUSLAM_K2_WAVES ? 16 : 0) + k] = (long long)wall_clock64();                       \
+            g_phase[(blockIdx.y == 104 / WAVES ? 16 : 0) + k] = (long long)wall_clock64();                       \
     } while (0)
 #else
 #define PHASE(k) do { } while (0)
@@ -85,10 +85,8 @@ __device__ long long g_wg[4096][2];          // entry / exit stamp of every work
 // a CU holds 8 of these waves.  As two 4-wave workgroups the CU runs two chains, and the later-dispatched workgroup
 // (its waves lose instruction arbitration to the older one's sweep) finishes 4 us after the first; as ONE 8-wave
 // workgroup the CU runs one chain and all eight tiles are swept together.
-#ifndef NUSLAM_K2_WAVES
-#define NUSLAM_K2_WAVES 8
-#endif
-constexpr int kPairWaves = NUSLAM_K2_WAVES;
+// The host picks WAVES = 8 when the whole grid is then resident in one generation (the single-filter, latency-bound
+// case) and WAVES = 4 otherwise (many filters: throughput-bound, and 8-wave groups idle more waves at small L).
 
 // LDS layout (doubles)
 enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 5x5: M1(set2[a], set1[q]) */,
@@ -96,8 +94,8 @@ enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 
        S2_OBS = 85 /* r1, phi1, r2, phi2 */, S2_K1S = 89 /* [a][2]: K1(set2[a], :) */, S2_NU1 = 100 /* z1 - z_hat1 */,
        S2_NU2 = 102 /* z2 - z_hat2 */, S2_WORDS = 104 };
 
-template <typename T>
-__global__ __launch_bounds__(64 * kPairWaves, 8 / kPairWaves) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
+template <typename T, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
                                                  T* __restrict__ Pout)
 {
     constexpr int CW = 16;
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(64 * kPairWaves, 8 / kPairWaves) void k_update2(Vie
 #ifdef NUSLAM_FLIP_Y
     const int strip = (gridDim.y - 1 - blockIdx.y) * 4 + wave;       // experiment: which half is slow, the data's or the dispatch's?
 #else
-    const int strip = blockIdx.y * kPairWaves + wave;
+    const int strip = blockIdx.y * WAVES + wave;
 #endif
     // Which wave carries which phase-A/B role rotates with the workgroup's dispatch generation.  Wave k of every
     // workgroup lands on SIMD k, the head chain is ~3000 wave64 fp64 instructions at 4 cycles each whatever the EXEC
@@ -431,7 +429,7 @@ __global__ __launch_bounds__(64 * kPairWaves, 8 / kPairWaves) void k_update2(Vie
     // ---- the sweep: both corrections on the tile in registers.  The ten prior-row values of a column (R1, R2) are
     // wave-uniform; they go through a per-wave LDS strip and come back as broadcast ds_read_b128 -- 5 LDS reads per
     // column instead of 20 v_readlane, which were a sixth of this kernel's VALU instructions.
-    __shared__ double sR[kPairWaves][CW][10];
+    __shared__ double sR[WAVES][CW][10];
     {
         double(*R)[10] = sR[wave];
         R[sj][sq] = vA;                               // r1[0..3] = rows 0, 1, 2, c1

@@ -44,6 +44,7 @@ struct nuslam_batch {
     int device = 0;
     int n = 0, L = 0, ld = 0, B = 0, dtype = 0;
     hipStream_t stream = nullptr;
+    int n_cu = 256;            // compute units of the device (MI355X: 256)
     double* state[2] = { nullptr, nullptr };
     int* ctrl[2] = { nullptr, nullptr };
     int sidx = 0, cidx = 0;
@@ -235,6 +236,17 @@ int associate_finish(nuslam_batch* h)
     return NUSLAM_OK;
 }
 
+// Waves per workgroup of the sweep kernels.  Every workgroup recomputes the correction's head, a serial chain of wave64
+// fp64 instructions, and a CU holds eight of these waves: with 8-wave workgroups a CU runs ONE chain and sweeps eight
+// tiles together.  That pays when the whole grid is resident at once (one generation: the single-filter case, where a
+// launch is latency-bound); with more workgroups than CUs the launch is throughput-bound and 4-wave groups idle fewer
+// waves at small L (L = 403: 7 % against 19 %).
+int sweep_waves(const nuslam_batch* h, int vec, int strips)
+{
+    const long long wgs8 = (long long)((h->ld + 64 * vec - 1) / (64 * vec)) * ((strips + 7) / 8) * h->B;
+    return wgs8 <= h->n_cu ? 8 : 4;
+}
+
 int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
 {
     if (h->deferred && mode != MODE_DA) {
@@ -257,12 +269,19 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     View v = h->view();
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + kSweepWaves - 1) / kSweepWaves, h->B), block(64 * kSweepWaves);
+    const int waves = sweep_waves(h, vec, strips);
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     int rc = NUSLAM_OK;
     const bool inl = (o.ids == nullptr);
 #define LAUNCH_UPDATE(MODE_, INL_)                                                                              \
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW, MODE_, INL_>, grid, block, v, o, total, \
-                               (const T*)h->P(), (T*)h->Palt())))
+    do {                                                                                                        \
+        if (waves == 8)                                                                                         \
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW, MODE_, INL_, 8>, grid, block, v, o, \
+                                       total, (const T*)h->P(), (T*)h->Palt())));                               \
+        else                                                                                                    \
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE, k_update<T, kSweepCW, MODE_, INL_, 4>, grid, block, v, o, \
+                                       total, (const T*)h->P(), (T*)h->Palt())));                               \
+    } while (0)
     if (mode == MODE_DA) LAUNCH_UPDATE(MODE_DA, true);
     else if (mode == MODE_FORCE) { if (inl) LAUNCH_UPDATE(MODE_FORCE, true); else LAUNCH_UPDATE(MODE_FORCE, false); }
     else { if (inl) LAUNCH_UPDATE(MODE_KNOWN, true); else LAUNCH_UPDATE(MODE_KNOWN, false); }
@@ -280,9 +299,13 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
     View v = h->view();
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + kPairWaves - 1) / kPairWaves, h->B), block(64 * kPairWaves);
+    const int waves = sweep_waves(h, vec, strips);
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
+    if (waves == 8)
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T, 8>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
+    else
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T, 4>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
     if (rc) return rc;
     h->sidx ^= 1;
     h->cidx ^= 1;
@@ -415,6 +438,8 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
     int rc = [&]() -> int {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cu = cus;
         const size_t sb = sizeof(double) * (size_t)B * h->ld;
         HIPCHK(hipMalloc(&h->state[0], sb));
         HIPCHK(hipMalloc(&h->state[1], sb));
