@@ -761,23 +761,26 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
     HIPCHK(hipStreamSynchronize(h->stream));
     free_trace(h);
     const size_t B = (size_t)h->B, T = (size_t)ticks, M = (size_t)m;
-    double* d_lm = nullptr; double* d_cmd = nullptr; unsigned long long* d_empty = nullptr;
+    struct Scratch {                                  // inputs of the two generator kernels; freed on every exit path
+        double* lm = nullptr; double* cmd = nullptr; unsigned long long* empty = nullptr;
+        ~Scratch() { if (lm) (void)hipFree(lm); if (cmd) (void)hipFree(cmd); if (empty) (void)hipFree(empty); }
+    } d;
     HIPCHK(hipMalloc(&h->tr_tw, sizeof(double) * B * T * 2));
     HIPCHK(hipMalloc(&h->tr_mx, sizeof(double) * B * T * M));
     HIPCHK(hipMalloc(&h->tr_my, sizeof(double) * B * T * M));
     HIPCHK(hipMalloc(&h->tr_ids, sizeof(int) * B * T * M));
     HIPCHK(hipMalloc(&h->tr_truth, sizeof(double) * B * T * 3));
-    HIPCHK(hipMalloc(&d_lm, sizeof(double) * 2 * n_world));
-    HIPCHK(hipMalloc(&d_cmd, sizeof(double) * 2 * T));
-    HIPCHK(hipMalloc(&d_empty, sizeof(unsigned long long)));
-    HIPCHK(hipMemcpy(d_lm, landmarks, sizeof(double) * 2 * n_world, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_cmd, cmd, sizeof(double) * 2 * T, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(d_empty, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&d.lm, sizeof(double) * 2 * n_world));
+    HIPCHK(hipMalloc(&d.cmd, sizeof(double) * 2 * T));
+    HIPCHK(hipMalloc(&d.empty, sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(d.lm, landmarks, sizeof(double) * 2 * n_world, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d.cmd, cmd, sizeof(double) * 2 * T, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(d.empty, 0, sizeof(unsigned long long)));
     SimArg a;
-    a.p = *p; a.lm = d_lm; a.cmd = d_cmd; a.n_world = n_world; a.ticks = ticks; a.m = m; a.B = h->B;
+    a.p = *p; a.lm = d.lm; a.cmd = d.cmd; a.n_world = n_world; a.ticks = ticks; a.m = m; a.B = h->B;
     a.seed = seed; a.first_filter = first_filter;
     a.tw = h->tr_tw; a.mx = h->tr_mx; a.my = h->tr_my; a.ids = h->tr_ids; a.truth = h->tr_truth;
-    a.empty = d_empty; a.raw = nullptr;
+    a.empty = d.empty; a.raw = nullptr;
     hipLaunchKernelGGL(k_sim_path, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, a);
     HIPCHK(hipGetLastError());
     const size_t lds = (size_t)n_world * 9;
@@ -787,9 +790,8 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
     hipLaunchKernelGGL(k_sim_markers, dim3(ticks, h->B), dim3(256), lds, h->stream, a);
     HIPCHK(hipGetLastError());
     unsigned long long empty = 0;
-    HIPCHK(hipMemcpyAsync(&empty, d_empty, sizeof(empty), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&empty, d.empty, sizeof(empty), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    (void)hipFree(d_lm); (void)hipFree(d_cmd); (void)hipFree(d_empty);
     if (empty_slots) *empty_slots = (long long)empty;
     h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = 0;
     if (!known_ids) {

@@ -256,6 +256,8 @@ class Batch:
             idp = ids.ctypes.data_as(_ip)
         _chk(lib().nuslam_batch_load_trace(self._h, T, m, _p(tw), _p(mx), _p(my), idp, 1 if bcast else 0),
              "batch_load_trace")
+        self._trace_shape = (T, m, ids is not None)
+        self._trace_generated = False
 
     def simulate(self, params, landmarks, cmd, m, seed, first_filter=0, known_ids=True):
         """Generate the resident trace on the device (tube_world.cpp:509-533 per filter): returns the number of
@@ -267,15 +269,19 @@ class Batch:
                                          int(m), int(seed), int(first_filter), 1 if known_ids else 0,
                                          C.byref(empty)), "batch_simulate")
         self._trace_shape = (cmd.shape[0], int(m), bool(known_ids))
+        self._trace_generated = True
         return empty.value
 
     def get_trace(self, b=0):
         """Filter b's generated trace: dict(tw (T,2), mx, my, ids (T,m), truth (T,3))."""
         T, m, known = self._trace_shape
-        tw = np.zeros((T, 2)); mx = np.zeros((T, m)); my = np.zeros((T, m)); truth = np.zeros((T, 3))
+        generated = getattr(self, "_trace_generated", False)
+        tw = np.zeros((T, 2)); mx = np.zeros((T, m)); my = np.zeros((T, m))
+        truth = np.zeros((T, 3)) if generated else None
         ids = np.zeros((T, m), dtype=np.int32) if known else None
         _chk(lib().nuslam_batch_get_trace(self._h, b, _p(tw), _p(mx), _p(my),
-                                          ids.ctypes.data_as(_ip) if known else None, _p(truth)), "batch_get_trace")
+                                          ids.ctypes.data_as(_ip) if known else None,
+                                          _p(truth) if generated else None), "batch_get_trace")
         return dict(tw=tw, mx=mx, my=my, ids=ids, truth=truth)
 
     def run(self, t_begin, t_end, total_landmarks=None):

@@ -280,3 +280,14 @@ def test_device_trace_data_association_needs_full_slots(hip):
     with pytest.raises(hip.NuslamError) as e:
         hip.Batch(1, 8, Q, R).simulate(gated, TUBES, _cmd(10), 6, 5, known_ids=False)
     assert e.value.code == hip.E_ARG
+
+
+@pytest.mark.gpu
+def test_get_trace_reads_back_a_host_loaded_trace(hip):
+    from nuslam_hip import synth
+    tr = synth.make_trace(6, 5, 3, landmarks=TUBES)
+    b = hip.Batch(2, 6, Q, R)
+    b.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+    got = b.get_trace(1)                                   # broadcast: every filter reads the one trace
+    assert np.array_equal(got["tw"], tr.tw[:, :2]) and np.array_equal(got["mx"], tr.mx)
+    assert np.array_equal(got["ids"], tr.ids) and got["truth"] is None
