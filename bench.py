@@ -295,7 +295,9 @@ def main():
         "warmup": W,
         "ms_per_step": 1e3 * dt / K,
         "higher_is_better": True,
-        "scaling": "weak",
+        # single filter: one replica per GPU (per-GPU work fixed -> weak); batch without --filters: 1024 filters split
+        # over the ranks (total work fixed -> strong); batch with --filters F: F filters per GPU (weak)
+        "scaling": "strong" if (args.workload == "batch" and not args.filters) else "weak",
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
