@@ -337,7 +337,12 @@ def main():
                            "avg_launch_us": 1e6 * avg_s, "launches": sweep_n, "corrections_per_launch": units,
                            "algorithmic_bytes_per_launch": per_launch_bytes,
                            "actual_bytes_per_launch": per_unit_bytes,
-                           "achieved_actual_bytes": per_unit_bytes / avg_s / 1e9}
+                           "achieved_actual_bytes": per_unit_bytes / avg_s / 1e9,
+                           "frac_actual_bytes": per_unit_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                           "note": "achieved/frac follow the algorithmic definition (2*L^2*w bytes per correction x "
+                                   "corrections per launch); a launch that applies two corrections in one pass moves each "
+                                   "byte once, so frac can exceed 1 -- achieved_actual_bytes / frac_actual_bytes / traffic "
+                                   "are what crosses the memory interface"}
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
