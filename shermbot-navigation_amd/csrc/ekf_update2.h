@@ -92,7 +92,7 @@ __device__ long long g_wg[4096][2];          // entry / exit stamp of every work
 enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 5x5: M1(set2[a], set1[q]) */,
        S2_R1S = 53 /* [q][b] 5x5: P0(set1[q], set2[b]) */, S2_DZ1 = 78, S2_ST1 = 80 /* th,x,y,lx2,ly2 after correction 1 */,
        S2_OBS = 85 /* r1, phi1, r2, phi2 */, S2_K1S = 89 /* [a][2]: K1(set2[a], :) */, S2_NU1 = 100 /* z1 - z_hat1 */,
-       S2_NU2 = 102 /* z2 - z_hat2 */, S2_WORDS = 104 };
+       S2_ZH2 = 102 /* range and un-rotated bearing of z_hat2 */, S2_WORDS = 104 };
 
 template <typename T, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
@@ -117,11 +117,15 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
     // the second workgroup of every CU finishes 4 us after the first (phase clock: exits at 10.3 / 14.6 us) while
     // SIMDs 1-3 idle.  256 = CUs of an MI355X; a different mapping costs speed, never correctness.
     const int role = wave;   // (rotation tried and measured: no gain)
-    const bool active = strip * CW < L;
-    const int j0 = active ? strip * CW : 0;
+    // Column strip 0 is half as wide as the others (8 columns): its wave also carries the state rows and, in workgroup
+    // (0,0), the heading's second re-normalisation; with a full tile it was the last wave of every launch to finish.
+    const int jstart = strip == 0 ? 0 : strip * CW - CW / 2;
+    const bool active = jstart < L;
+    const int j0 = active ? jstart : 0;
     const bool rows_ok = row0 < ld;
     const int rowc = rows_ok ? row0 : 0;
-    const int ncol = (L - j0) < CW ? (L - j0) : CW;
+    const int wcol = strip == 0 ? CW / 2 : CW;
+    const int ncol = (L - j0) < wcol ? (L - j0) : wcol;
 
     __shared__ double sh[S2_WORDS];
     __shared__ int sh_i[4];                       // singular flag of correction 1, of correction 2, status
@@ -319,7 +323,11 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
             sh[S2_NU1] = dz10; sh[S2_NU1 + 1] = dz11;
             sh_i[1] = sing2; sh_i[2] = status;
         }
-    } else if (role == 3 && blockIdx.y == 0) {     // consumed by the state rows only (column strip 0)
+    } else if ((role == 3 || role == 2) && blockIdx.y == 0) {
+        // consumed by the state rows only (column strip 0's workgroups).  Two waves share the chain: role 3 re-normalises
+        // the heading (sin, cos, atan2), role 2 turns the corrected landmark offset into polar form (sqrt; atan2, sin,
+        // cos, atan2); the last step of computeTheoreticalMeasurement, normalize(bearing - heading), needs both and is
+        // done by the state-owning wave after the barrier.
         const int sg1 = sh_i[0];
         const double dz10 = sg1 ? 0.0 : sh[S2_OBS] - sh[S2_DZ1], dz11 = sg1 ? 0.0 : sh[S2_OBS + 1] - sh[S2_DZ1 + 1];
         const double s0v[5] = { lane_bcast(v_st, 0), lane_bcast(v_st, 1), lane_bcast(v_st, 2), lane_bcast(v_st, 5),
@@ -332,13 +340,13 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
             acc = fma(sh[S2_K1S + 2 * a + 1], dz11, acc);
             st1[a] = s0v[a] + acc;
         }
-        if (!sg1) st1[0] = normalize_angle(st1[0]);                    // update() re-normalises the heading (:276)
-        double zr, zb;
-        measurement(st1[0], st1[1], st1[2], st1[3], st1[4], zr, zb);   // :265 of correction 2
-        if (lane == 0) {
-            sh[S2_ST1] = st1[0];                                        // the heading row's value after correction 1
-            sh[S2_NU2] = sh[S2_OBS + 2] - zr;
-            sh[S2_NU2 + 1] = sh[S2_OBS + 3] - zb;
+        if (role == 3) {
+            if (!sg1) st1[0] = normalize_angle(st1[0]);                // update() re-normalises the heading (:276)
+            if (lane == 0) sh[S2_ST1] = st1[0];                        // the heading row's value after correction 1
+        } else {
+            double zr, zb;                                             // computeTheoreticalMeasurement (:150-160) up to
+            cartesian2polar(st1[3] - st1[1], st1[4] - st1[2], zr, zb); // the polar form of the offset
+            if (lane == 0) { sh[S2_ZH2] = zr; sh[S2_ZH2 + 1] = zb; }
         }
     }
     PHASE(5);
@@ -355,7 +363,12 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
 
     // the innovations only feed the state: column strip 0's waves
     const bool owns_state = (strip == 0);
-    const double dz20 = sing2 ? 0.0 : sh[S2_NU2], dz21 = sing2 ? 0.0 : sh[S2_NU2 + 1];
+    double dz20 = 0.0, dz21 = 0.0;
+    if (owns_state && !sing2) {
+        const double zb = normalize_angle(sh[S2_ZH2 + 1] - sh[S2_ST1]);     // the last step of z_hat2 (:159)
+        dz20 = sh[S2_OBS + 2] - sh[S2_ZH2];
+        dz21 = sh[S2_OBS + 3] - zb;
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         int* co = v.c_out + b * C_WORDS;
         co[C_SEEN] = seen_in; co[C_SEEN_CACHED] = cached_in; co[C_BRK] = brk_in; co[C_STATUS] = sh_i[2];
@@ -439,8 +452,7 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
     __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the strip is this wave's own, no barrier needed
     T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
     PHASE(8);
-#pragma unroll
-    for (int jj = 0; jj < CW; ++jj) {
+    auto sweep_column = [&](int jj) {
         double r1v[5], r2v[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) { r1v[q] = sR[wave][jj][q]; r2v[q] = sR[wave][jj][5 + q]; }
@@ -452,6 +464,12 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
             out.v[e] = (T)sweep_entry(m2[e], r2v, p1, bef2[e], aft2[e]);
         }
         if (jj < ncol && rows_ok) store_stream(Pw + (size_t)jj * ld, out);
+    };
+#pragma unroll
+    for (int jj = 0; jj < CW / 2; ++jj) sweep_column(jj);
+    if (ncol > CW / 2) {                               // wave-uniform: strip 0 has only the first half
+#pragma unroll
+        for (int jj = CW / 2; jj < CW; ++jj) sweep_column(jj);
     }
 #ifdef NUSLAM_PHASE_CLOCK
     PHASE(9);

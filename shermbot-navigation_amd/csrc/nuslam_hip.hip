@@ -298,7 +298,7 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
 {
     View v = h->view();
     const int vec = 16 / (int)h->esize();
-    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    const int strips = 1 + (h->L - kSweepCW / 2 + kSweepCW - 1) / kSweepCW;    // strip 0 is half as wide (ekf_update2.h)
     const int waves = sweep_waves(h, vec, strips);
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     int rc = NUSLAM_OK;
