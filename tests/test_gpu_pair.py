@@ -55,7 +55,8 @@ def _bind(hip):
 
 
 @pytest.mark.parametrize("group", GROUPS)
-@pytest.mark.parametrize("n,m,dtype", [(10, 10, 0), (37, 16, 0), (64, 7, 0), (40, 16, 1), (127, 9, 0)])
+@pytest.mark.parametrize("n,m,dtype", [(2, 2, 0), (3, 3, 1), (10, 10, 0), (37, 16, 0), (64, 7, 0), (40, 16, 1), (127, 9, 0),
+                                       (300, 8, 0)])
 def test_pair_equals_two_singles_bitwise(hip, n, m, dtype, group):
     o, gp, gs, lm = warm_pair_of_filters(hip, n, dtype, group=group)
     tr = synth.make_trace(n, 5, m, landmarks=lm)
