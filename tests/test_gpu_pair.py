@@ -205,3 +205,30 @@ def test_pair_with_per_filter_ids_in_resident_trace(hip):
         assert np.array_equal(s1, s2) and np.array_equal(c1, c2) and k1 == k2
     # and the filters really are different trials
     assert not np.array_equal(res[0][0][0], res[0][1][0])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_four_wave_groups_when_the_grid_exceeds_one_generation(hip, dtype):
+    """More workgroups than CUs (300 filters): the host picks the 4-wave variants of both sweep kernels.  Paired and
+    unpaired runs must still agree bit for bit, and filter b must equal the single-filter path (8-wave variant)."""
+    B, n, m, T = 300, 10, 6, 3
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, T, m, landmarks=lm)
+    bx, by, wid = synth.warmup_observations(lm)
+    res = []
+    for pairing in (True, False):
+        bt = hip.Batch(B, n, Q, R, dtype=dtype)
+        bt.set_pairing(pairing)
+        bt.load_trace(np.zeros((1, 2)), bx[None], by[None], wid[None], bcast=True)
+        bt.run(0, 1)
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+        bt.run(0, T)
+        res.append([(bt.state(b), bt.cov(b)) for b in (0, 149, 299)])
+        assert bt.status()[1] == 0
+    for (s1, c1), (s2, c2) in zip(*res):
+        assert np.array_equal(s1, s2) and np.array_equal(c1, c2)
+    g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+    g.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+    for t in range(T):
+        g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+    assert np.array_equal(g.state, res[0][1][0]) and np.array_equal(g.cov, res[0][1][1])
