@@ -113,7 +113,7 @@ def cpu_baseline(n, m, tr, budget_s, warm_state):
             "sample": "%d tick(s) (1 predict + %d updates each) of the same N=%d trace from the same post-initialisation "
                       "snapshot, reference algebra (two L^3 GEMMs per predict, one per update), %.1f s; faster of "
                       "{oracle-c: %.2f, numpy-blas: %.2f} updates/s" % (done, m, n, dt, cands["oracle-c"][0], cands["numpy-blas"][0]),
-            "ms_per_step": 1e3 * dt / done}, o
+            "ms_per_step": 1e3 * dt / done}, o, cands["oracle-c"][1]
 
 
 def main():
@@ -371,9 +371,24 @@ def main():
     if deferred_extra is not None:
         out["deferred_mode"] = deferred_extra
     if warm_state is not None and args.cpu_seconds > 0 and args.workload == "ekf1000":
-        cb, _ = cpu_baseline(n, m, synth.make_trace(n, W + 3 * K, m, seed=12345), args.cpu_seconds, warm_state)
+        ptr = synth.make_trace(n, W + 3 * K, m, seed=12345)
+        cb, orc, orc_ticks = cpu_baseline(n, m, ptr, args.cpu_seconds, warm_state)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        # parity in the same run: the ticks the CPU oracle (dense reference algebra) just ran, replayed on the GPU from
+        # the same post-initialisation snapshot through the same kernels the timed region used
+        g2 = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
+        g2.restore(*warm_state)
+        for t in range(orc_ticks):
+            g2.tick(ptr.tw[t], ptr.mx[t], ptr.my[t], known_ids=ptr.ids[t], want_ids=False)
+        gs, gP, os_, oP = g2.state, g2.cov, orc.state.copy(), orc.cov.copy()
+        floor = 1e-12 * np.abs(oP).max()
+        out["parity"] = {"against": "oracle/nuslam_oracle.c, dense mode (the reference's algebra; EKF parity unpinned, see DESIGN.md)",
+                         "ticks": int(orc_ticks), "corrections": int(orc_ticks * m),
+                         "max_rel_err_state": float((np.abs(gs - os_) / np.maximum(np.abs(os_), 1e-12)).max()),
+                         "max_rel_err_cov": float((np.abs(gP - oP) / np.maximum(np.abs(oP), floor)).max()),
+                         "rel_frobenius_cov": float(np.linalg.norm(gP - oP) / np.linalg.norm(oP)),
+                         "seen_equal": bool(g2.seen == orc.seen), "tolerance": 1e-6}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
