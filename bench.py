@@ -177,7 +177,7 @@ def main():
         bt = ekf.as_batch()
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
         ekf.sync()
-        warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None
+        warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and world == 1 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None   # cpu_baseline: N=1 only
         if args.workload == "ekf5000":
             # a DENSE Jacobian kept resident in HBM: the reference's A = I + B for the first twist plus a small dense
             # random perturbation -- every operand non-zero, because MFMA loops on mostly-zero operands hold a higher
