@@ -168,8 +168,9 @@ typedef struct nuslam_sim_params {
  * of global filter index first_filter + b, so a sharded batch reproduces the unsharded one.  Each tick keeps the (at
  * most m) nearest tubes within max_range in tube order; unused slots get id -1, which the tick's decision chain skips
  * (slam.cpp:298-300).  known_ids != 0: the trace carries the tube index + 1 as the landmark id; 0: data association
- * (then every slot must be filled: NUSLAM_E_ARG if one is not).  empty_slots (may be NULL) receives the number of
- * unused slots.  Synchronises. */
+ * (the ids then only mark which slots hold a marker; an empty slot is a marker the node never received, so
+ * associateLandmark is not called for it).  empty_slots (may be NULL) receives the number of unused slots.
+ * Synchronises. */
 int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
                           const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
                           int known_ids, long long* empty_slots);

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_update(View v, ObsArg o, int tot
     if (MODE == MODE_DA) {                                // associateLandmark's verdict, from the reduced key
         const Assoc a = decode_association(v.n, seen, brk, status0, v.akey[2 * b + v.aslot]);
         id_raw = a.id; seen_now = a.new_seen; status_now = a.new_status;
+        // a generated trace has a fixed number of marker slots per tick; a slot without a marker (presence word < 0)
+        // is a marker the node never received: associateLandmark is not called for it (slam.cpp:279), nothing moves
+        if (o.ids != nullptr && o.ids[b * o.stride + o.off] < 0) { id_raw = -1; seen_now = seen; status_now = status0; }
     } else {
         id_raw = INLINE_ID ? o.id0 : o.ids[b * o.stride + o.off];
     }

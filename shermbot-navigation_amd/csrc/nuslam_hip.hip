@@ -60,6 +60,7 @@ struct nuslam_batch {
     // resident trace
     double* tr_tw = nullptr; double* tr_mx = nullptr; double* tr_my = nullptr; int* tr_ids = nullptr;
     int tr_ticks = 0, tr_m = 0, tr_bcast = 0;
+    bool tr_presence_only = false;   // data-association trace: tr_ids only says which marker slots are filled (id > 0)
     double* tr_truth = nullptr;   // generated traces only: the simulated robot's pose after each tick
     std::vector<int> h_ids;    // host copy of a broadcast trace's ids: passed inline so k_update needs no id load
     std::vector<int> h_ids_pf; // host copy of a per-filter trace's ids [B][ticks][m]: only to decide pairing per tick
@@ -723,6 +724,7 @@ void free_trace(nuslam_batch* h)
         if (p) (void)hipFree(p);
     h->tr_tw = h->tr_mx = h->tr_my = h->tr_truth = nullptr; h->tr_ids = nullptr;
     h->tr_ticks = h->tr_m = h->tr_bcast = 0;
+    h->tr_presence_only = false;
     h->h_ids.clear();
     h->h_ids_pf.clear();
 }
@@ -794,12 +796,8 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
     HIPCHK(hipStreamSynchronize(h->stream));
     if (empty_slots) *empty_slots = (long long)empty;
     h->tr_ticks = ticks; h->tr_m = m; h->tr_bcast = 0;
-    if (!known_ids) {
-        // data association reads no ids: an unused slot would be taken for a marker at the robot's own position
-        (void)hipFree(h->tr_ids);
-        h->tr_ids = nullptr;
-        if (empty) { free_trace(h); return NUSLAM_E_ARG; }
-    } else {
+    h->tr_presence_only = !known_ids;
+    if (known_ids) {
         // the host keeps the ids only to decide, tick by tick, whether every correction is a plain one (pairing)
         std::vector<int>& dst = h->B == 1 ? h->h_ids : h->h_ids_pf;
         dst.resize(B * T * M);
@@ -869,7 +867,7 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
         const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
         const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m;
-        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr, total_landmarks, hid, nullptr, nullptr, pfid,
+        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
                      (long long)h->tr_ticks * h->tr_m);
     }
     h->id_log = saved_log;
