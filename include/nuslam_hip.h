@@ -162,6 +162,11 @@ typedef struct nuslam_sim_params {
     double tube_var;                   /* constant offset added to both marker coordinates, :311-312 */
     double marker_sigma;               /* extension: Gaussian marker noise on top (0 = the reference's behaviour) */
     double max_range;                  /* range gate :300-307; <= 0: every tube every tick (what the slam node sees) */
+    double lidar;                      /* != 0: the markers of a tick come from the simulated lidar instead of set_rel_markers:
+                                          simulate_lidar_scanner (tube_world.cpp:405-471) -> the landmarks node's chain
+                                          clusterPoints -> classifyCluster -> circleFit (nuslam/src/landmarks.cpp:63, 82-108),
+                                          all on the device; data association only (scan markers carry no identity) */
+    double lidar_min_range, lidar_max_range;   /* nuturtlesim/config/scan_params.yaml: minimum_range 0.05, maximum_range 1.0 */
 } nuslam_sim_params;
 /* Generate `ticks` ticks for every filter: landmarks = {x0, y0, x1, y1, ...} (n_world tubes, shared by all filters),
  * cmd = ticks x (dth, dx) commanded body twists (the /cmd_vel stream, shared).  Filter b draws from the random streams
@@ -177,6 +182,8 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
 /* Read filter b's resident trace back (any pointer may be NULL): tw ticks x 2, mx / my / ids ticks x m, truth
  * ticks x 3 (theta, x, y of the simulated robot after each tick; only for generated traces). */
 int nuslam_batch_get_trace(nuslam_batch_t* h, int b, double* tw, double* mx, double* my, int* ids, double* truth);
+/* the simulated lidar scan (360 ranges, robot frame) of filter b at tick t; only after a generation with lidar != 0 */
+int nuslam_batch_get_scan(nuslam_batch_t* h, int b, int tick, float out_ranges[360]);
 /* bit-exact hook for the generator's RNG: the Philox4x32-10 block of (seed, counter), computed on the device */
 int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4], int device);
 

@@ -100,6 +100,9 @@ typedef struct {
     double tube_var;                   /* constant offset added to both marker coordinates, :311-312 */
     double marker_sigma;               /* extension: Gaussian marker noise on top (0 = the reference's behaviour) */
     double max_range;                  /* range gate :300-307; <= 0 disables it (the slam node ignores DELETE) */
+    double lidar;                      /* != 0: markers come from the simulated lidar scan through the landmarks node's
+                                          cluster / classify / circle-fit chain instead of set_rel_markers (unused here) */
+    double lidar_min_range, lidar_max_range;   /* scan_params.yaml minimum_range / maximum_range */
 } orc_sim_params;
 void   orc_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4]);
 void   orc_sim_normal_pair(unsigned long long seed, unsigned filter, unsigned tick, unsigned stream, unsigned idx,
@@ -111,6 +114,10 @@ void   orc_sim_normal_pair(unsigned long long seed, unsigned filter, unsigned ti
 long long orc_simulate(const orc_sim_params* p, const double* landmarks, int n, const double* cmd, int ticks, int m,
                        unsigned long long seed, unsigned filter, double* tw, double* mx, double* my, int* ids,
                        double* truth, double* joints);
+
+/* simulate_lidar_scanner, tube_world.cpp:405-471 (see sim_oracle.c) */
+void   orc_sim_scan(const double* landmarks, int n, double tube_radius, double max_scan_range, double x, double y,
+                    double th, float ranges[360]);
 
 int     orc_len(const orc_ekf* e);
 int     orc_n(const orc_ekf* e);

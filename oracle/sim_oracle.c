@@ -173,3 +173,51 @@ long long orc_simulate(const orc_sim_params* p, const double* landmarks, int n, 
     free(keep);
     return empty;
 }
+
+/* ------------------------------------------------------------------ the lidar
+ * simulate_lidar_scanner, nuturtlesim/src/tube_world.cpp:405-471, as it stands (the author's "still need to fix lidar
+ * function" included): for every tube, 54 one-degree rays around round(rad2deg(atan2(yt - y1, xt - x1))) with
+ * (x1, y1) = robot - tube -- not the bearing of the tube, but that is what the node computes --, the ray/circle
+ * intersection in the tube's frame (:430-452; `dy / fabs(dy)` is NaN for a horizontal ray and such a ray then never
+ * updates a range), the scan index (i - int(rad2deg(theta))) mod 360, ranges stored as float and initialised to
+ * max_scan_range + 1.  No walls, no noise, no minimum range: the reference function has none either. */
+void orc_sim_scan(const double* landmarks, int n, double tube_radius, double max_scan_range, double x, double y,
+                  double th, float ranges[360])
+{
+    const double PI = 3.14159265358979323846;
+    for (int k = 0; k < 360; ++k) ranges[k] = (float)(max_scan_range + 1);          /* :416 */
+    for (int t = 0; t < n; ++t) {
+        const double xt = landmarks[2 * t], yt = landmarks[2 * t + 1];
+        const double x1 = x - xt, y1 = y - yt;                                       /* :423-424 */
+        const int tube_angle = (int)round(((double)180 / PI) * atan2(yt - y1, xt - x1));   /* :426 */
+        for (int i = tube_angle - 27; i < tube_angle + 27; ++i) {                    /* :428 */
+            const double x2 = x1 + max_scan_range * cos((PI / (double)180) * i);
+            const double y2 = y1 + max_scan_range * sin((PI / (double)180) * i);
+            const double dx = x2 - x1, dy = y2 - y1;
+            const double dr = sqrt((dx * dx) + (dy * dy));
+            const double det = x1 * y2 - x2 * y1;
+            const double dis = ((tube_radius * tube_radius) * (dr * dr)) - (det * det);
+            double distance;
+            if (fabs(dis) < 1e-5) {                                                  /* :438-442 */
+                const double ix = (det * dy) / (dr * dr);
+                const double iy = -(det * dx) / (dr * dr);
+                distance = sqrt(((ix - x1) * (ix - x1)) + ((iy - y1) * (iy - y1)));
+            } else if (dis > 0) {                                                    /* :443-453 */
+                const double root = sqrt(((tube_radius * tube_radius) * (dr * dr)) - (det * det));
+                const double ix1 = ((det * dy) + ((dy / fabs(dy)) * dx * root)) / (dr * dr);
+                const double iy1 = (-(det * dx) + fabs(dy) * root) / (dr * dr);
+                const double d1 = sqrt(((ix1 - x1) * (ix1 - x1)) + ((iy1 - y1) * (iy1 - y1)));
+                const double ix2 = ((det * dy) - ((dy / fabs(dy)) * dx * root)) / (dr * dr);
+                const double iy2 = (-(det * dx) - fabs(dy) * root) / (dr * dr);
+                const double d2 = sqrt(((ix2 - x1) * (ix2 - x1)) + ((iy2 - y1) * (iy2 - y1)));
+                distance = (d2 < d1) ? d2 : d1;                                      /* std::min(dist1, dist2) */
+            } else {
+                distance = max_scan_range + 1;                                       /* :455 */
+            }
+            int ind = (i - (int)(((double)180 / PI) * th)) % 360;                    /* :458 */
+            if (ind < 0) ind += 360;
+            if (distance < ranges[ind]) ranges[ind] = (float)distance;               /* :461-463 */
+        }
+    }
+}
+

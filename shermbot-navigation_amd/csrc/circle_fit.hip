@@ -89,14 +89,16 @@ __device__ inline int solve4(const double* M, const double b[4], double x[4])
 }
 
 // one wave per cluster; 4 clusters per 256-thread workgroup
+// cluster cl owns points [offsets[cl], ends ? ends[cl] : offsets[cl + 1])
 __global__ __launch_bounds__(256) void k_circle_fit(int n_clusters, const int* __restrict__ offsets,
+                                                    const int* __restrict__ ends,
                                                     const double* __restrict__ xs, const double* __restrict__ ys,
                                                     double* __restrict__ work, double* __restrict__ out, int* __restrict__ status)
 {
     const int lane = threadIdx.x & 63;
     const int cl = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cl >= n_clusters) return;
-    const int p0 = offsets[cl], n = offsets[cl + 1] - p0;
+    const int p0 = offsets[cl], n = (ends ? ends[cl] : offsets[cl + 1]) - p0;
     if (n < 4) {                                                    // circle_fit_library.cpp:73-77
         if (lane == 0) { status[cl] = 1; out[3 * cl] = out[3 * cl + 1] = out[3 * cl + 2] = 0.0; }
         return;
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void k_circle_fit(int n_clusters, const int* _
 
 // classifyCluster, :208-250 -- one wave per cluster
 __global__ __launch_bounds__(256) void k_classify(int n_clusters, const int* __restrict__ offsets,
+                                                  const int* __restrict__ ends,
                                                   const double* __restrict__ xs, const double* __restrict__ ys,
                                                   int* __restrict__ is_circle, double* __restrict__ std_dev)
 {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256) void k_classify(int n_clusters, const int* __r
     const int lane = threadIdx.x & 63;
     const int cl = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cl >= n_clusters) return;
-    const int p0 = offsets[cl], n = offsets[cl + 1] - p0;
+    const int p0 = offsets[cl], n = (ends ? ends[cl] : offsets[cl + 1]) - p0;
     if (n < 3) { if (lane == 0) { is_circle[cl] = 0; std_dev[cl] = 0.0; } return; }
     const double* X = xs + p0;
     const double* Yv = ys + p0;
@@ -247,9 +250,153 @@ __global__ __launch_bounds__(256) void k_classify(int n_clusters, const int* __r
     if (lane == 0) { std_dev[cl] = sd; is_circle[cl] = sd < 10 ? 1 : 0; }
 }
 
+// ---------------------------------------------------------------- scans -> markers (the landmarks node on the device)
+// circle_fit::clusterPoints, circle_fit_library.cpp:136-206, one lane per 360-ray scan (a sequential walk: each step
+// decides from the previous one), with the reference's quirks kept: the wrap-around point goes to cluster 0, an
+// unfinished cluster at the end of the walk is lost, and the erase loop (:197-204) skips the element after each one
+// it erases.  Surviving clusters are written contiguously, in push order, into the scan's 360-point region:
+// cluster c of scan s owns points [cbeg[s * kMaxScanClusters + c], cend[...]) of px / py.
+constexpr int kMaxScanClusters = 32;
+
+__global__ __launch_bounds__(64) void k_scan_clusters(int n_scans, const float* __restrict__ scans, double min_range,
+                                                      double max_range, double* __restrict__ px, double* __restrict__ py,
+                                                      int* __restrict__ cbeg, int* __restrict__ cend,
+                                                      int* __restrict__ tmp_i, double* __restrict__ tmp_d,
+                                                      int* __restrict__ overflow)
+{
+    const double PI = 3.14159265358979323846;
+    const double threshold = 0.04;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_scans) return;
+    const float* ranges = scans + (size_t)s * 360;
+    int* cl_of = tmp_i + (size_t)s * 1080;                // cluster of the k-th emitted point
+    int* sizes = cl_of + 360;                             // points per pushed cluster
+    int* alive = cl_of + 720;                             // the vector of clusters during the erase loop
+    double* ex = tmp_d + (size_t)s * 720;                 // emitted points, in emission order
+    double* ey = ex + 360;
+    for (int k = 0; k < 360; ++k) sizes[k] = 0;
+    int curr = 0, npts = 0, nclusters = 0, open = 0;
+    while (curr < 360) {
+        const float rc = ranges[curr];
+        if (((double)rc > max_range) || ((double)rc < min_range)) { curr += 1; continue; }     // :148-152
+        const int next = (curr + 1) % 360;
+        const double cd = rc, nd = ranges[next];
+        const double x = (double)rc * cos((PI / (double)180) * curr);                          // :161-162
+        const double y = (double)rc * sin((PI / (double)180) * curr);
+        if (fabs(cd - nd) < threshold) {
+            if (next < curr) {                            // wrap-around: the point joins the first cluster (:169-172)
+                if (nclusters > 0) { ex[npts] = x; ey[npts] = y; cl_of[npts] = 0; sizes[0]++; npts++; }
+            } else {
+                ex[npts] = x; ey[npts] = y; cl_of[npts] = nclusters; sizes[nclusters]++; npts++;
+                open = 1;
+                curr += 1;
+            }
+        } else {
+            ex[npts] = x; ey[npts] = y; cl_of[npts] = nclusters; sizes[nclusters]++; npts++;
+            nclusters++;
+            open = 0;
+            curr += 1;
+        }
+        if (next < curr) break;
+    }
+    if (open)                                             // the open cluster is never pushed: its points are lost
+        for (int k = 0; k < npts; ++k) if (cl_of[k] == nclusters) cl_of[k] = -1;
+    // erase loop :197-204: erasing element i shifts the rest down while i still advances (the next one is skipped)
+    int cnt = nclusters;
+    for (int i = 0; i < cnt; ++i) alive[i] = i;
+    for (int i = 0; i < cnt; ++i)
+        if (sizes[alive[i]] < 3) {
+            for (int j = i; j < cnt - 1; ++j) alive[j] = alive[j + 1];
+            cnt--;
+        }
+    // gather the survivors, cluster by cluster, points in emission order
+    const int base = s * 360;
+    double* X = px + (size_t)base;
+    double* Y = py + (size_t)base;
+    int* cb = cbeg + (size_t)s * kMaxScanClusters;
+    int* ce = cend + (size_t)s * kMaxScanClusters;
+    int kept = 0;
+    for (int c = 0; c < kMaxScanClusters; ++c) {
+        cb[c] = base + kept;
+        if (c < cnt) {
+            const int id = alive[c];
+            for (int k = 0; k < npts; ++k)
+                if (cl_of[k] == id) { X[kept] = ex[k]; Y[kept] = ey[k]; kept++; }
+        }
+        ce[c] = base + kept;
+    }
+    if (cnt > kMaxScanClusters) atomicAdd(overflow, 1);
+}
+
+// the node's loop body, nuslam/src/landmarks.cpp:82-108, per scan: clusters in order; keep a cluster if classifyCluster
+// says circle, circleFit returned a marker (id >= 0) and its radius is at most 1; its centre becomes the next marker.
+__global__ __launch_bounds__(64) void k_scan_markers(int n_scans, int m, const int* __restrict__ is_circle,
+                                                     const int* __restrict__ status, const double* __restrict__ fit,
+                                                     double* __restrict__ mx, double* __restrict__ my, int* __restrict__ ids,
+                                                     unsigned long long* __restrict__ empty, int* __restrict__ overflow)
+{
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_scans) return;
+    int slot = 0;
+    for (int c = 0; c < kMaxScanClusters; ++c) {
+        const int cl = s * kMaxScanClusters + c;
+        if (!is_circle[cl]) continue;                                            // :86
+        if (status[cl] != 0) continue;                                           // marker.id < 0, :91-93
+        if (fit[3 * cl + 2] > 1) continue;                                       // marker.scale.x / 2 > 1, :95-97
+        if (slot >= m) { atomicAdd(overflow, 1); break; }
+        mx[(size_t)s * m + slot] = fit[3 * cl];
+        my[(size_t)s * m + slot] = fit[3 * cl + 1];
+        ids[(size_t)s * m + slot] = slot + 1;                                    // marker.id = running index (:103); > 0 = present
+        slot++;
+    }
+    if (slot < m) atomicAdd(empty, (unsigned long long)(m - slot));
+    for (; slot < m; ++slot) { mx[(size_t)s * m + slot] = 0.0; my[(size_t)s * m + slot] = 0.0; ids[(size_t)s * m + slot] = -1; }
+}
+
 #define CHK(expr) do { if ((expr) != hipSuccess) { rc = NUSLAM_E_HIP; goto done; } } while (0)
 
 } // namespace
+
+namespace nuslam {
+
+// Scans (device, [n_scans][360] float) -> marker slots (device, [n_scans][m]): k_scan_clusters, k_classify,
+// k_circle_fit, k_scan_markers on `stream`.  overflow_out: scans with more than kMaxScanClusters clusters or more than
+// m accepted markers (their surplus is dropped).  Returns a nuslam_status.
+int scan_to_markers(hipStream_t stream, const float* d_scans, int n_scans, double min_range, double max_range, int m,
+                    double* d_mx, double* d_my, int* d_ids, unsigned long long* d_empty, int* overflow_out)
+{
+    int rc = NUSLAM_OK;
+    const size_t S = (size_t)n_scans, NC = S * kMaxScanClusters;
+    double *px = nullptr, *py = nullptr, *tmp_d = nullptr, *work = nullptr, *fit = nullptr, *sd = nullptr;
+    int *cbeg = nullptr, *cend = nullptr, *tmp_i = nullptr, *status = nullptr, *circ = nullptr, *ovf = nullptr;
+    int h_ovf = 0;
+    CHK(hipMalloc(&px, sizeof(double) * S * 360)); CHK(hipMalloc(&py, sizeof(double) * S * 360));
+    CHK(hipMalloc(&tmp_d, sizeof(double) * S * 720)); CHK(hipMalloc(&tmp_i, sizeof(int) * S * 1080));
+    CHK(hipMalloc(&work, sizeof(double) * 4 * S * 360));
+    CHK(hipMalloc(&cbeg, sizeof(int) * NC)); CHK(hipMalloc(&cend, sizeof(int) * NC));
+    CHK(hipMalloc(&fit, sizeof(double) * 3 * NC)); CHK(hipMalloc(&sd, sizeof(double) * NC));
+    CHK(hipMalloc(&status, sizeof(int) * NC)); CHK(hipMalloc(&circ, sizeof(int) * NC));
+    CHK(hipMalloc(&ovf, sizeof(int)));
+    CHK(hipMemsetAsync(ovf, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_scan_clusters, dim3((n_scans + 63) / 64), dim3(64), 0, stream, n_scans, d_scans, min_range, max_range,
+                       px, py, cbeg, cend, tmp_i, tmp_d, ovf);
+    hipLaunchKernelGGL(k_classify, dim3(((int)NC + 3) / 4), dim3(256), 0, stream, (int)NC, (const int*)cbeg, (const int*)cend,
+                       (const double*)px, (const double*)py, circ, sd);
+    hipLaunchKernelGGL(k_circle_fit, dim3(((int)NC + 3) / 4), dim3(256), 0, stream, (int)NC, (const int*)cbeg, (const int*)cend,
+                       (const double*)px, (const double*)py, work, fit, status);
+    hipLaunchKernelGGL(k_scan_markers, dim3((n_scans + 63) / 64), dim3(64), 0, stream, n_scans, m, (const int*)circ,
+                       (const int*)status, (const double*)fit, d_mx, d_my, d_ids, d_empty, ovf);
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(&h_ovf, ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+    CHK(hipStreamSynchronize(stream));
+    if (overflow_out) *overflow_out = h_ovf;
+done:
+    void* ptrs[] = { px, py, tmp_d, tmp_i, work, cbeg, cend, fit, sd, status, circ, ovf };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return rc;
+}
+
+} // namespace nuslam
 
 extern "C" {
 
@@ -286,9 +433,9 @@ int nuslam_circle_fit_batch(int n_clusters, const int* offsets, const double* xs
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     CHK(hipEventRecord(e0, nullptr));
     hipLaunchKernelGGL(k_circle_fit, dim3((n_clusters + 3) / 4), dim3(256), 0, nullptr, n_clusters, (const int*)d_off,
-                       (const double*)d_x, (const double*)d_y, d_work, d_out, d_status);
+                       (const int*)nullptr, (const double*)d_x, (const double*)d_y, d_work, d_out, d_status);
     hipLaunchKernelGGL(k_classify, dim3((n_clusters + 3) / 4), dim3(256), 0, nullptr, n_clusters, (const int*)d_off,
-                       (const double*)d_x, (const double*)d_y, d_circ, d_sd);
+                       (const int*)nullptr, (const double*)d_x, (const double*)d_y, d_circ, d_sd);
     CHK(hipGetLastError());
     CHK(hipEventRecord(e1, nullptr));
     CHK(hipEventSynchronize(e1));

@@ -249,4 +249,68 @@ __global__ __launch_bounds__(256) void k_sim_markers(SimArg a)
     if (tid == 0 && kept < m) atomicAdd(a.empty, (unsigned long long)(m - kept));
 }
 
+// ---------------------------------------------------------------- the lidar
+// simulate_lidar_scanner, nuturtlesim/src/tube_world.cpp:405-471, as it stands (the author's "still need to fix lidar
+// function" included): for every tube, 54 one-degree rays around round(rad2deg(atan2(yt - y1, xt - x1))) with
+// (x1, y1) = robot - tube, the ray / circle intersection in the tube's frame (:430-452; `dy / fabs(dy)` is NaN for a
+// horizontal ray, and such a ray then never updates a range), the scan index (i - int(rad2deg(theta))) mod 360,
+// ranges stored as float and initialised to max_scan_range + 1.  No walls, no noise, no minimum range: the reference
+// function has none.  One workgroup per (tick, filter); the (tube, ray) pairs are spread over the lanes and the
+// reference's sequential "keep the smaller" becomes a 64-bit unsigned minimum in LDS (non-negative doubles order
+// like their bit patterns), converted to float once at the end.
+__global__ __launch_bounds__(256) void k_sim_scan(SimArg a, float* __restrict__ scans)
+{
+    const double PI = 3.14159265358979323846;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const nuslam_sim_params& p = a.p;
+    __shared__ unsigned long long sh_min[360];
+    const size_t o = (size_t)b * a.ticks + t;
+    const double th = a.truth[3 * o + 0], x = a.truth[3 * o + 1], y = a.truth[3 * o + 2];
+    const double max_scan = p.lidar_max_range;
+    const float init = (float)(max_scan + 1);                                   // :416
+    for (int k = tid; k < 360; k += 256) sh_min[k] = (unsigned long long)__double_as_longlong((double)init);
+    __syncthreads();
+    const int shift = (int)(((double)180 / PI) * th);                           // int(rad2deg(theta)), :458
+    const long long items = (long long)a.n_world * 54;
+    for (long long it = tid; it < items; it += 256) {
+        const int tube = (int)(it / 54), ray = (int)(it % 54);
+        const double xt = a.lm[2 * tube], yt = a.lm[2 * tube + 1];
+        const double x1 = x - xt, y1 = y - yt;                                   // :423-424
+        const int tube_angle = (int)round(((double)180 / PI) * atan2(yt - y1, xt - x1));   // :426
+        const int i = tube_angle - 27 + ray;                                     // :428
+        const double x2 = x1 + max_scan * cos((PI / (double)180) * i);
+        const double y2 = y1 + max_scan * sin((PI / (double)180) * i);
+        const double dx = x2 - x1, dy = y2 - y1;
+        const double dr = sqrt((dx * dx) + (dy * dy));
+        const double det = x1 * y2 - x2 * y1;
+        const double r2 = p.tube_radius * p.tube_radius;
+        const double dis = (r2 * (dr * dr)) - (det * det);
+        double distance;
+        if (fabs(dis) < 1e-5) {                                                  // :438-442
+            const double ix = (det * dy) / (dr * dr);
+            const double iy = -(det * dx) / (dr * dr);
+            distance = sqrt(((ix - x1) * (ix - x1)) + ((iy - y1) * (iy - y1)));
+        } else if (dis > 0) {                                                    // :443-453
+            const double root = sqrt((r2 * (dr * dr)) - (det * det));
+            const double ix1 = ((det * dy) + ((dy / fabs(dy)) * dx * root)) / (dr * dr);
+            const double iy1 = (-(det * dx) + fabs(dy) * root) / (dr * dr);
+            const double d1 = sqrt(((ix1 - x1) * (ix1 - x1)) + ((iy1 - y1) * (iy1 - y1)));
+            const double ix2 = ((det * dy) - ((dy / fabs(dy)) * dx * root)) / (dr * dr);
+            const double iy2 = (-(det * dx) - fabs(dy) * root) / (dr * dr);
+            const double d2 = sqrt(((ix2 - x1) * (ix2 - x1)) + ((iy2 - y1) * (iy2 - y1)));
+            distance = (d2 < d1) ? d2 : d1;                                      // std::min(dist1, dist2)
+        } else {
+            distance = max_scan + 1;                                             // :455
+        }
+        int ind = (i - shift) % 360;                                             // :458
+        if (ind < 0) ind += 360;
+        if (distance < (double)init)                                             // NaN never passes, as in `distance < ranges[ind]`
+            atomicMin(&sh_min[ind], (unsigned long long)__double_as_longlong(distance));
+    }
+    __syncthreads();
+    for (int k = tid; k < 360; k += 256)
+        scans[o * 360 + k] = (float)__longlong_as_double((long long)sh_min[k]);  // :461-463 store as float
+}
+
 } // namespace nuslam

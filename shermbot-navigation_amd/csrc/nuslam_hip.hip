@@ -21,6 +21,12 @@
 
 using namespace nuslam;
 
+namespace nuslam {
+// circle_fit.hip: simulated scans -> marker slots, the landmarks node's chain on the device
+int scan_to_markers(hipStream_t stream, const float* d_scans, int n_scans, double min_range, double max_range, int m,
+                    double* d_mx, double* d_my, int* d_ids, unsigned long long* d_empty, int* overflow_out);
+}
+
 namespace {
 
 thread_local std::string g_hip_err;
@@ -62,6 +68,7 @@ struct nuslam_batch {
     int tr_ticks = 0, tr_m = 0, tr_bcast = 0;
     bool tr_presence_only = false;   // data-association trace: tr_ids only says which marker slots are filled (id > 0)
     double* tr_truth = nullptr;   // generated traces only: the simulated robot's pose after each tick
+    float* tr_scan = nullptr;     // generated with lidar != 0: [B][ticks][360] simulated ranges
     std::vector<int> h_ids;    // host copy of a broadcast trace's ids: passed inline so k_update needs no id load
     std::vector<int> h_ids_pf; // host copy of a per-filter trace's ids [B][ticks][m]: only to decide pairing per tick
     // staging for nuslam_ekf_tick (one filter, m observations)
@@ -411,7 +418,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -719,10 +726,10 @@ namespace {
 
 void free_trace(nuslam_batch* h)
 {
-    void* olds[] = { h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth };
+    void* olds[] = { h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan };
     for (void* p : olds)
         if (p) (void)hipFree(p);
-    h->tr_tw = h->tr_mx = h->tr_my = h->tr_truth = nullptr; h->tr_ids = nullptr;
+    h->tr_tw = h->tr_mx = h->tr_my = h->tr_truth = nullptr; h->tr_ids = nullptr; h->tr_scan = nullptr;
     h->tr_ticks = h->tr_m = h->tr_bcast = 0;
     h->tr_presence_only = false;
     h->h_ids.clear();
@@ -789,8 +796,21 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
     if (lds > 48 * 1024)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sim_markers),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sim_markers, dim3(ticks, h->B), dim3(256), lds, h->stream, a);
-    HIPCHK(hipGetLastError());
+    if (p->lidar != 0.0) {
+        // markers from the simulated lidar through the landmarks node's chain; they carry no identity
+        if (known_ids) { free_trace(h); return NUSLAM_E_ARG; }
+        HIPCHK(hipMalloc(&h->tr_scan, sizeof(float) * B * T * 360));
+        hipLaunchKernelGGL(k_sim_scan, dim3(ticks, h->B), dim3(256), 0, h->stream, a, h->tr_scan);
+        HIPCHK(hipGetLastError());
+        int overflow = 0;
+        const int src = scan_to_markers(h->stream, h->tr_scan, (int)(B * T), p->lidar_min_range, p->lidar_max_range, m,
+                                        h->tr_mx, h->tr_my, h->tr_ids, d.empty, &overflow);
+        if (src) { g_hip_err = "scan_to_markers failed"; return src; }
+        if (overflow) { free_trace(h); return NUSLAM_E_ARG; }      // more markers in a scan than slots: raise m
+    } else {
+        hipLaunchKernelGGL(k_sim_markers, dim3(ticks, h->B), dim3(256), lds, h->stream, a);
+        HIPCHK(hipGetLastError());
+    }
     unsigned long long empty = 0;
     HIPCHK(hipMemcpyAsync(&empty, d.empty, sizeof(empty), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -803,6 +823,15 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
         dst.resize(B * T * M);
         HIPCHK(hipMemcpy(dst.data(), h->tr_ids, sizeof(int) * B * T * M, hipMemcpyDeviceToHost));
     }
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_get_scan(nuslam_batch_t* h, int b, int tick, float out[360])
+{
+    if (!h || !h->tr_scan || !out || b < 0 || b >= h->B || tick < 0 || tick >= h->tr_ticks) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->tr_scan + ((size_t)b * h->tr_ticks + tick) * 360, sizeof(float) * 360, hipMemcpyDeviceToHost));
     return NUSLAM_OK;
 }
 

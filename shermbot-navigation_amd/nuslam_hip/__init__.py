@@ -73,6 +73,7 @@ SYMBOLS = [
     ("nuslam_batch_simulate", C.c_int, [_vp, C.c_void_p, _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_ulonglong, C.c_uint,
                                         C.c_int, C.POINTER(C.c_longlong)]),
     ("nuslam_batch_get_trace", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip, _dp]),
+    ("nuslam_batch_get_scan", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("nuslam_philox4x32_10", C.c_int, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
 ]
 
@@ -81,11 +82,13 @@ class SimParams(C.Structure):
     """nuslam_sim_params (include/nuslam_hip.h).  Defaults: nuturtlesim/config/tube_world_params.yaml and
     nuturtle_description/config/diff_params.yaml of the reference."""
     _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
-                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range")]
+                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range",
+                                          "lidar", "lidar_min_range", "lidar_max_range")]
 
     def __init__(self, **kw):
         d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
-                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0)
+                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0,
+                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0)
         d.update(kw)
         super().__init__(**d)
 
@@ -268,12 +271,18 @@ class Batch:
         _chk(lib().nuslam_batch_simulate(self._h, C.addressof(params), _p(lm), lm.size // 2, _p(cmd), cmd.shape[0],
                                          int(m), int(seed), int(first_filter), 1 if known_ids else 0,
                                          C.byref(empty)), "batch_simulate")
-        self._trace_shape = (cmd.shape[0], int(m), bool(known_ids))
+        self._trace_shape = (cmd.shape[0], int(m), True)      # generated traces always carry ids (identity or presence)
         self._trace_generated = True
         return empty.value
 
+    def get_scan(self, b, tick):
+        out = np.zeros(360, dtype=np.float32)
+        _chk(lib().nuslam_batch_get_scan(self._h, b, tick, out.ctypes.data_as(C.POINTER(C.c_float))), "batch_get_scan")
+        return out
+
     def get_trace(self, b=0):
-        """Filter b's generated trace: dict(tw (T,2), mx, my, ids (T,m), truth (T,3))."""
+        """Filter b's resident trace: dict(tw (T,2), mx, my, ids (T,m), truth (T,3)).  For a generated data-association
+        trace `ids` only marks the filled slots (> 0) and the empty ones (-1)."""
         T, m, known = self._trace_shape
         generated = getattr(self, "_trace_generated", False)
         tw = np.zeros((T, 2)); mx = np.zeros((T, m)); my = np.zeros((T, m))

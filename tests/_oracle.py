@@ -42,11 +42,13 @@ class SimParams(C.Structure):
     """orc_sim_params (oracle/nuslam_oracle.h); include/nuslam_hip.h's nuslam_sim_params has the same layout.
     Defaults: nuturtlesim/config/tube_world_params.yaml + nuturtle_description/config/diff_params.yaml."""
     _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
-                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range")]
+                                          "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range",
+                                          "lidar", "lidar_min_range", "lidar_max_range")]
 
     def __init__(self, **kw):
         d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
-                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0)
+                 tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0,
+                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0)
         d.update(kw)
         super().__init__(**d)
 
@@ -100,6 +102,8 @@ def lib():
         _up = C.POINTER(C.c_uint)
         L.orc_philox4x32_10.argtypes = [_up, _up, _up]
         L.orc_sim_normal_pair.argtypes = [C.c_ulonglong, C.c_uint, C.c_uint, C.c_uint, C.c_uint, _dp]
+        L.orc_sim_scan.argtypes = [_dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.POINTER(C.c_float)]
         L.orc_simulate.restype = C.c_longlong
         L.orc_simulate.argtypes = [C.POINTER(SimParams), _dp, C.c_int, _dp, C.c_int, C.c_int, C.c_ulonglong,
                                    C.c_uint, _dp, _dp, _dp, _ip, _dp, _dp]
@@ -161,6 +165,30 @@ def simulate(params, landmarks, cmd, m, seed, filt=0):
     if empty < 0:
         raise OracleError(ORC_E_ARG)
     return dict(tw=tw, mx=mx[:, :m], my=my[:, :m], ids=ids[:, :m], truth=truth, joints=joints, empty=int(empty))
+
+
+def sim_scan(landmarks, tube_radius, max_scan_range, pose_th_x_y):
+    """simulate_lidar_scanner (tube_world.cpp:405-471): 360 float ranges for the robot at pose (th, x, y)."""
+    lm = np.ascontiguousarray(landmarks, dtype=np.float64).reshape(-1)
+    out = np.zeros(360, dtype=np.float32)
+    th, x, y = pose_th_x_y
+    lib().orc_sim_scan(_p(lm), lm.size // 2, tube_radius, max_scan_range, x, y, th, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def scan_markers(ranges, min_range, max_range):
+    """The landmarks node's loop body (nuslam/src/landmarks.cpp:63, 82-108): clusterPoints -> classifyCluster ->
+    circleFit -> keep fits with marker.id >= 0 and radius <= 1.  Returns the marker centres, in cluster order."""
+    out = []
+    for xs, ys in cluster_points(ranges, min_range, max_range):
+        ok, _ = classify_cluster(xs, ys)
+        if not ok:
+            continue
+        st, cx, cy, r = circle_fit(xs, ys)
+        if st != 0 or r > 1:
+            continue
+        out.append((cx, cy))
+    return out
 
 
 def map_to_odom(odom, state3):

@@ -302,3 +302,72 @@ def test_get_trace_reads_back_a_host_loaded_trace(hip):
     got = b.get_trace(1)                                   # broadcast: every filter reads the one trace
     assert np.array_equal(got["tw"], tr.tw[:, :2]) and np.array_equal(got["mx"], tr.mx)
     assert np.array_equal(got["ids"], tr.ids) and got["truth"] is None
+
+
+# ------------------------------------------------------------------ the lidar and the landmarks node's chain
+def test_lidar_oracle_sees_the_tubes_in_range():
+    """simulate_lidar_scanner (tube_world.cpp:405-471) as restated: from the origin the two tubes within 1 m show up
+    as dips of the right depth, everything else reads max_range + 1; the landmarks chain recovers their centres."""
+    r = O.sim_scan(TUBES, 0.0381, 1.0, (0.0, 0.0, 0.0))
+    assert r.dtype == np.float32 and np.all(r[np.r_[0:40, 60:120, 150:200]] == np.float32(2.0))
+    d = np.hypot(0.5, 0.5) - 0.0381
+    assert abs(float(r[45]) - d) < 1e-6 and abs(float(r[225]) - d) < 1e-6
+    ms = O.scan_markers(r, 0.05, 1.0)
+    assert len(ms) == 2
+    assert np.allclose(ms[0], (0.5, 0.5), atol=1e-6) and np.allclose(ms[1], (-0.5, -0.5), atol=1e-6)
+    # robot frame: turn the robot by 90 degrees and the tube that was at 45 degrees shows up at -45 (= 315)
+    r2 = O.sim_scan(TUBES, 0.0381, 1.0, (np.pi / 2, 0.0, 0.0))
+    assert abs(float(r2[315]) - d) < 1e-6
+
+
+@pytest.mark.gpu
+def test_device_lidar_pipeline_matches_oracle(hip):
+    """k_sim_scan -> k_scan_clusters -> k_classify -> k_circle_fit -> k_scan_markers against the oracle's restatement
+    of tube_world.cpp:405-471 and nuslam/src/landmarks.cpp:63, 82-108, scan by scan and marker by marker."""
+    kw = dict(lidar=1.0, slip_min=1.0, slip_max=1.0)
+    ph, po = _same_params(hip, **kw)
+    B, n, m, T = 3, 8, 6, 40
+    cmd = _cmd(T, 0.35, 0.3)
+    b = hip.Batch(B, n, np.diag([1e-4] * 3), R)
+    empty = b.simulate(ph, TUBES, cmd, m, 31, known_ids=False)
+    total_empty = 0
+    for f in range(B):
+        want = O.simulate(po, TUBES, cmd, m, 31, filt=f)
+        got = b.get_trace(f)
+        assert np.allclose(got["truth"], want["truth"], atol=1e-12, rtol=0)
+        for t in range(T):
+            scan_o = O.sim_scan(TUBES, po.tube_radius, po.lidar_max_range, want["truth"][t])
+            scan_g = b.get_scan(f, t)
+            assert np.allclose(scan_g, scan_o, atol=2e-6, rtol=0), (f, t)
+            ms = O.scan_markers(scan_o, po.lidar_min_range, po.lidar_max_range)
+            present = got["ids"][t] > 0
+            assert present.sum() == len(ms), (f, t, got["ids"][t], ms)
+            assert np.array_equal(got["ids"][t][present], np.arange(1, len(ms) + 1))   # packed to the front
+            for k, (cx, cy) in enumerate(ms):
+                assert abs(got["mx"][t, k] - cx) < 1e-7 and abs(got["my"][t, k] - cy) < 1e-7
+            total_empty += m - len(ms)
+    assert empty == total_empty and empty > 0
+
+
+@pytest.mark.gpu
+def test_slam_from_device_lidar_markers(hip):
+    """The whole reference chain on the device -- simulator, lidar, landmark extraction, EKF-SLAM with unknown data
+    association -- against the same chain in the oracle."""
+    kw = dict(lidar=1.0, slip_min=1.0, slip_max=1.0)
+    ph, po = _same_params(hip, **kw)
+    n, m, T = 8, 6, 60
+    cmd = _cmd(T, 0.3, 0.25)
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    b = hip.Batch(2, n, Qs, R)
+    b.simulate(ph, TUBES, cmd, m, 5, known_ids=False)
+    b.run(0, T, total_landmarks=n)
+    assert b.status()[1] == 0
+    want = O.simulate(po, TUBES, cmd, m, 5, filt=1)
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Qs, R, O.ORC_STRUCTURED)
+    for t in range(T):
+        scan = O.sim_scan(TUBES, po.tube_radius, po.lidar_max_range, want["truth"][t])
+        ms = O.scan_markers(scan, po.lidar_min_range, po.lidar_max_range)
+        o.tick(tw=np.array([want["tw"][t, 0], want["tw"][t, 1], 0.0]), mx=np.array([p[0] for p in ms]),
+               my=np.array([p[1] for p in ms]))
+    assert b.seen(1) == o.seen and o.seen >= 2
+    assert np.allclose(b.state(1), o.state, atol=5e-3, rtol=0)            # cold start: INT_MAX conditioning (DESIGN.md)
