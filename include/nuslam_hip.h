@@ -37,7 +37,9 @@ typedef enum {
     NUSLAM_E_SINGULAR = 3,  /* innovation covariance not invertible (Armadillo inv(): std::runtime_error, :270) */
     NUSLAM_E_HIP = 4,       /* a HIP runtime call failed; nuslam_last_hip_error() has the text */
     NUSLAM_E_NODEV = 5,     /* no HIP device available */
-    NUSLAM_E_NOMEM = 6
+    NUSLAM_E_NOMEM = 6,
+    NUSLAM_E_CAPACITY = 7   /* a fixed-size device table is too small for this input (nuslam_batch_simulate with lidar:
+                               a scan left more clusters than the per-scan table of 64 holds) */
 } nuslam_status;
 
 typedef enum { NUSLAM_F64 = 0, NUSLAM_F32 = 1 } nuslam_dtype; /* storage type of the covariance in HBM */
@@ -129,8 +131,11 @@ int nuslam_batch_get_seen(nuslam_batch_t* h, int b, int* seen);
 int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const double* cov, int ld, int seen);
 int nuslam_batch_sync(nuslam_batch_t* h);
 int nuslam_batch_status(nuslam_batch_t* h, int clear, int* first_bad_filter, int* status_out);
-/* Batch statistics for the Monte-Carlo reduction: out = { sum_b state (len), sum_b state^2 (len),
- * sum_b trace(P), count } -- 2*len + 2 doubles, accumulated in filter order (deterministic). */
+/* Batch statistics for the Monte-Carlo reduction (SURVEY 8e): out = { sum_b state (len), sum_b state^2 (len),
+ * sum_b (estimate - truth)^2 of the pose (theta wrapped, x, y: 3), sum_b NEES (e^T P[0:3,0:3]^-1 e), sum_b trace(P),
+ * count } -- 2*len + 6 doubles, every sum accumulated in filter order (deterministic).  The truth is the simulated
+ * robot's pose after the last tick nuslam_batch_run applied (traces made by nuslam_batch_simulate keep it); with any
+ * other trace the four truth-dependent entries are 0. */
 int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len);
 /* a one-filter view for the single-filter API above is the batch of size 1: */
 int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do not destroy */

@@ -210,6 +210,13 @@ int orc_circle_fit(const double* xs, const double* ys, int n, double* work, doub
 int orc_classify_cluster(const double* xs, const double* ys, int n, double* std_dev_out)
 {
     const double PI = 3.14159265358979323846;
+    if (n < 3) {
+        /* no inscribed angle: angles.size() == 0 (unsigned), the loops of :217,:231,:237 do not run and
+         * std_dev = sqrt(0.0 / 0) = NaN, NaN < 10 is false (:243-249).  1- and 2-point clusters do reach this
+         * function: the erase loop of clusterPoints exempts the cluster that follows a discarded one. */
+        if (std_dev_out) *std_dev_out = NAN;
+        return 0;
+    }
     const double p2x = xs[0], p2y = ys[0], p3x = xs[n - 1], p3y = ys[n - 1];
     const int cnt = n - 2;
     double mean = 0.0;

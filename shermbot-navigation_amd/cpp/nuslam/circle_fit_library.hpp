@@ -81,37 +81,66 @@ namespace circle_fit
     /// circle / not circle by the spread of the inscribed angles (circle_fit_library.cpp:208-250)
     inline bool classifyCluster(std::vector<Point> cluster) { return fitClusters({ cluster })[0].is_circle; }
 
-    /// group the rays of one 360-degree scan into clusters (circle_fit_library.cpp:136-206), host side
+    /// Group the rays of one 360-degree scan into clusters (behaviour of circle_fit_library.cpp:136-206), host side.
+    /// Worked on ray indices: a cluster is the set of in-range rays in [first, last] (+ ray 359 when the scan wraps into
+    /// the first cluster); points are only materialised for the clusters that survive.  The reference's observable
+    /// quirks are kept: a cluster closes after ray a when |r[a] - r[(a+1) % 360]| >= 0.04 whether or not ray a+1 is in
+    /// range; a wrapping ray 359 joins cluster 0 and whatever was still open is lost; the discard pass removes a
+    /// small cluster and then exempts the one that follows it (:197-204 erase while the index advances).
     inline std::vector<std::vector<Point>> clusterPoints(std::vector<float> ranges, double minRange, double maxRange)
     {
-        std::vector<std::vector<Point>> clusters;
-        std::vector<Point> current_cluster;
-        const double threshold = 0.04;
-        int curr_angle = 0;
-        while (curr_angle < 360) {
-            if ((ranges[curr_angle] > maxRange) || (ranges[curr_angle] < minRange)) { curr_angle += 1; continue; }
-            const int next_angle = (curr_angle + 1) % 360;
-            const double curr_dist = ranges[curr_angle], next_dist = ranges[next_angle];
-            Point point;
-            point.x = ranges[curr_angle] * std::cos(rigid2d::deg2rad(curr_angle));
-            point.y = ranges[curr_angle] * std::sin(rigid2d::deg2rad(curr_angle));
-            if (std::fabs(curr_dist - next_dist) < threshold) {
-                if (next_angle < curr_angle) {                       // 359 -> 0 wrap-around joins the first cluster
-                    if (!clusters.empty()) clusters[0].push_back(point);
-                } else {
-                    current_cluster.push_back(point);
-                    curr_angle += 1;
-                }
-            } else {
-                current_cluster.push_back(point);
-                clusters.push_back(current_cluster);
-                current_cluster.clear();
-                curr_angle += 1;
+        constexpr int kRays = 360;
+        constexpr double kGap = 0.04;
+        struct Span { int first, last, members; bool takes_wrap; };
+        auto usable = [&](int a) { return !(ranges[a] > maxRange) && !(ranges[a] < minRange); };
+        auto joined = [&](int a) {
+            return std::fabs(static_cast<double>(ranges[a]) - static_cast<double>(ranges[(a + 1) % kRays])) < kGap;
+        };
+
+        // pass 1: spans of ray indices
+        std::vector<Span> spans;
+        int open_first = -1, open_members = 0;
+        for (int a = 0; a < kRays; ++a) {
+            if (!usable(a)) continue;
+            const bool link = joined(a);
+            if (a == kRays - 1 && link) {                            // wrap-around: ray 359 belongs to the first cluster
+                if (!spans.empty()) { spans[0].takes_wrap = true; spans[0].members += 1; }
+                open_first = -1;                                     // the open span is never closed: dropped
+                break;
             }
-            if (next_angle < curr_angle) break;
+            if (open_first < 0) { open_first = a; open_members = 0; }
+            open_members += 1;
+            if (!link) {
+                spans.push_back(Span{ open_first, a, open_members, false });
+                open_first = -1;
+            }
         }
-        for (std::size_t i = 0; i < clusters.size(); i++)            // :197-204 (erase shifts, the index still advances)
-            if (clusters[i].size() < 3) clusters.erase(clusters.begin() + i);
+
+        // pass 2: the discard rule, as a keep mask
+        std::vector<char> keep(spans.size(), 1);
+        bool exempt = false;
+        for (std::size_t k = 0; k < spans.size(); ++k) {
+            if (exempt) { exempt = false; continue; }
+            if (spans[k].members < 3) { keep[k] = 0; exempt = true; }
+        }
+
+        // pass 3: points of the survivors
+        auto point_of = [&](int a) {
+            Point p;
+            p.x = ranges[a] * std::cos(rigid2d::deg2rad(a));
+            p.y = ranges[a] * std::sin(rigid2d::deg2rad(a));
+            return p;
+        };
+        std::vector<std::vector<Point>> clusters;
+        for (std::size_t k = 0; k < spans.size(); ++k) {
+            if (!keep[k]) continue;
+            std::vector<Point> pts;
+            pts.reserve(static_cast<std::size_t>(spans[k].members));
+            for (int a = spans[k].first; a <= spans[k].last; ++a)
+                if (usable(a)) pts.push_back(point_of(a));
+            if (spans[k].takes_wrap) pts.push_back(point_of(kRays - 1));
+            clusters.push_back(std::move(pts));
+        }
         return clusters;
     }
 }

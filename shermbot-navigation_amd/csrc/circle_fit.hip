@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_classify(int n_clusters, const int* __r
     const int cl = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cl >= n_clusters) return;
     const int p0 = offsets[cl], n = (ends ? ends[cl] : offsets[cl + 1]) - p0;
-    if (n < 3) { if (lane == 0) { is_circle[cl] = 0; std_dev[cl] = 0.0; } return; }
+    if (n < 3) { if (lane == 0) { is_circle[cl] = 0; std_dev[cl] = __builtin_nan(""); } return; }   // sqrt(0/0): NaN < 10 is false (:243-249)
     const double* X = xs + p0;
     const double* Yv = ys + p0;
     const double p2x = X[0], p2y = Yv[0], p3x = X[n - 1], p3y = Yv[n - 1];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_classify(int n_clusters, const int* __r
 // unfinished cluster at the end of the walk is lost, and the erase loop (:197-204) skips the element after each one
 // it erases.  Surviving clusters are written contiguously, in push order, into the scan's 360-point region:
 // cluster c of scan s owns points [cbeg[s * kMaxScanClusters + c], cend[...]) of px / py.
-constexpr int kMaxScanClusters = 32;
+constexpr int kMaxScanClusters = 64;
 
 __global__ __launch_bounds__(64) void k_scan_clusters(int n_scans, const float* __restrict__ scans, double min_range,
                                                       double max_range, double* __restrict__ px, double* __restrict__ py,
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_scan_clusters(int n_scans, const float* 
         }
         ce[c] = base + kept;
     }
-    if (cnt > kMaxScanClusters) atomicAdd(overflow, 1);
+    if (cnt > kMaxScanClusters) atomicAdd(overflow + 0, 1);       // [0]: cluster table too small for this scan
 }
 
 // the node's loop body, nuslam/src/landmarks.cpp:82-108, per scan: clusters in order; keep a cluster if classifyCluster
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64) void k_scan_markers(int n_scans, int m, const i
         if (!is_circle[cl]) continue;                                            // :86
         if (status[cl] != 0) continue;                                           // marker.id < 0, :91-93
         if (fit[3 * cl + 2] > 1) continue;                                       // marker.scale.x / 2 > 1, :95-97
-        if (slot >= m) { atomicAdd(overflow, 1); break; }
+        if (slot >= m) { atomicAdd(overflow + 1, 1); break; }       // [1]: more accepted markers than slots
         mx[(size_t)s * m + slot] = fit[3 * cl];
         my[(size_t)s * m + slot] = fit[3 * cl + 1];
         ids[(size_t)s * m + slot] = slot + 1;                                    // marker.id = running index (:103); > 0 = present
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(64) void k_scan_markers(int n_scans, int m, const i
 namespace nuslam {
 
 // Scans (device, [n_scans][360] float) -> marker slots (device, [n_scans][m]): k_scan_clusters, k_classify,
-// k_circle_fit, k_scan_markers on `stream`.  overflow_out: scans with more than kMaxScanClusters clusters or more than
-// m accepted markers (their surplus is dropped).  Returns a nuslam_status.
+// k_circle_fit, k_scan_markers on `stream`.  overflow_out[0]: scans with more than kMaxScanClusters surviving clusters,
+// overflow_out[1]: scans with more than m accepted markers (the surplus is dropped in both cases).  Returns a nuslam_status.
 int scan_to_markers(hipStream_t stream, const float* d_scans, int n_scans, double min_range, double max_range, int m,
                     double* d_mx, double* d_my, int* d_ids, unsigned long long* d_empty, int* overflow_out)
 {
@@ -369,15 +369,15 @@ int scan_to_markers(hipStream_t stream, const float* d_scans, int n_scans, doubl
     const size_t S = (size_t)n_scans, NC = S * kMaxScanClusters;
     double *px = nullptr, *py = nullptr, *tmp_d = nullptr, *work = nullptr, *fit = nullptr, *sd = nullptr;
     int *cbeg = nullptr, *cend = nullptr, *tmp_i = nullptr, *status = nullptr, *circ = nullptr, *ovf = nullptr;
-    int h_ovf = 0;
+    int h_ovf[2] = { 0, 0 };
     CHK(hipMalloc(&px, sizeof(double) * S * 360)); CHK(hipMalloc(&py, sizeof(double) * S * 360));
     CHK(hipMalloc(&tmp_d, sizeof(double) * S * 720)); CHK(hipMalloc(&tmp_i, sizeof(int) * S * 1080));
     CHK(hipMalloc(&work, sizeof(double) * 4 * S * 360));
     CHK(hipMalloc(&cbeg, sizeof(int) * NC)); CHK(hipMalloc(&cend, sizeof(int) * NC));
     CHK(hipMalloc(&fit, sizeof(double) * 3 * NC)); CHK(hipMalloc(&sd, sizeof(double) * NC));
     CHK(hipMalloc(&status, sizeof(int) * NC)); CHK(hipMalloc(&circ, sizeof(int) * NC));
-    CHK(hipMalloc(&ovf, sizeof(int)));
-    CHK(hipMemsetAsync(ovf, 0, sizeof(int), stream));
+    CHK(hipMalloc(&ovf, 2 * sizeof(int)));
+    CHK(hipMemsetAsync(ovf, 0, 2 * sizeof(int), stream));
     hipLaunchKernelGGL(k_scan_clusters, dim3((n_scans + 63) / 64), dim3(64), 0, stream, n_scans, d_scans, min_range, max_range,
                        px, py, cbeg, cend, tmp_i, tmp_d, ovf);
     hipLaunchKernelGGL(k_classify, dim3(((int)NC + 3) / 4), dim3(256), 0, stream, (int)NC, (const int*)cbeg, (const int*)cend,
@@ -387,9 +387,9 @@ int scan_to_markers(hipStream_t stream, const float* d_scans, int n_scans, doubl
     hipLaunchKernelGGL(k_scan_markers, dim3((n_scans + 63) / 64), dim3(64), 0, stream, n_scans, m, (const int*)circ,
                        (const int*)status, (const double*)fit, d_mx, d_my, d_ids, d_empty, ovf);
     CHK(hipGetLastError());
-    CHK(hipMemcpyAsync(&h_ovf, ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+    CHK(hipMemcpyAsync(h_ovf, ovf, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     CHK(hipStreamSynchronize(stream));
-    if (overflow_out) *overflow_out = h_ovf;
+    if (overflow_out) { overflow_out[0] = h_ovf[0]; overflow_out[1] = h_ovf[1]; }
 done:
     void* ptrs[] = { px, py, tmp_d, tmp_i, work, cbeg, cend, fit, sd, status, circ, ovf };
     for (void* p : ptrs) if (p) (void)hipFree(p);

@@ -271,9 +271,43 @@ __global__ __launch_bounds__(256) void k_trace(View v, const T* __restrict__ P, 
     if (threadIdx.x == 0) tr[b] = sh[0];
 }
 
-// out = { sum_b state[i] (L), sum_b state[i]^2 (L), sum_b trace, B } accumulated in filter order.
+// Per-filter Monte-Carlo terms against the simulated truth (generated traces keep the true pose of every tick):
+// e = (wrap(theta_hat - theta), x_hat - x, y_hat - y) and NEES = e^T Ppose^-1 e with Ppose = P[0:3, 0:3] (3x3 inverse
+// by cofactors, fp64).  pe[4 b + {0,1,2}] = e^2, pe[4 b + 3] = NEES.  truth == nullptr: zeros.
+template <typename T>
+__global__ __launch_bounds__(64) void k_pose_error(View v, const T* __restrict__ P, const double* __restrict__ s_cur,
+                                                   const double* __restrict__ truth, long long truth_stride,
+                                                   long long truth_off, double* __restrict__ pe)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= v.B) return;
+    double* o = pe + 4 * (size_t)b;
+    if (truth == nullptr) { o[0] = o[1] = o[2] = o[3] = 0.0; return; }
+    const double* tp = truth + (size_t)b * truth_stride + truth_off;     // (theta, x, y) after the last tick run
+    const double* s = s_cur + (size_t)b * v.ld;
+    const double e0 = normalize_angle(s[0] - tp[0]), e1 = s[1] - tp[1], e2 = s[2] - tp[2];
+    const T* Pb = P + (size_t)b * v.p_stride;
+    double a[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) a[i][j] = (double)Pb[(size_t)j * v.ld + i];
+    const double c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1];
+    const double c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2];
+    const double c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+    const double det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+    const double i00 = c00 / det, i01 = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det, i02 = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+    const double i10 = c01 / det, i11 = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det, i12 = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+    const double i20 = c02 / det, i21 = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det, i22 = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+    const double q0 = i00 * e0 + i01 * e1 + i02 * e2;
+    const double q1 = i10 * e0 + i11 * e1 + i12 * e2;
+    const double q2 = i20 * e0 + i21 * e1 + i22 * e2;
+    o[0] = e0 * e0; o[1] = e1 * e1; o[2] = e2 * e2;
+    o[3] = e0 * q0 + e1 * q1 + e2 * q2;
+}
+
+// out = { sum_b state[i] (L), sum_b state[i]^2 (L), sum_b (est - truth)^2 of the pose (3), sum_b NEES, sum_b trace(P), B }
+//  -- 2 L + 6 doubles, every sum accumulated in filter order (deterministic).
 __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict__ s_cur, const double* __restrict__ tr,
-                                               double* __restrict__ out)
+                                               const double* __restrict__ pe, double* __restrict__ out)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < v.L) {
@@ -286,11 +320,16 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
         out[t] = a;
         out[v.L + t] = a2;
     }
-    if (t == 0) {
+    if (t < 4) {
+        double a = 0.0;
+        for (int b = 0; b < v.B; ++b) a = a + pe[4 * (size_t)b + t];
+        out[2 * v.L + t] = a;
+    }
+    if (t == 4) {
         double a = 0.0;
         for (int b = 0; b < v.B; ++b) a = a + tr[b];
-        out[2 * v.L] = a;
-        out[2 * v.L + 1] = (double)v.B;
+        out[2 * v.L + 4] = a;
+        out[2 * v.L + 5] = (double)v.B;
     }
 }
 

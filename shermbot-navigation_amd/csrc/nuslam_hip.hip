@@ -61,7 +61,9 @@ struct nuslam_batch {
     int* akey = nullptr;       // [B][2] association key slots
     int aslot = 0;
     double* tr = nullptr;      // per-filter trace scratch
-    double* stats = nullptr;   // 2L + 2
+    double* stats = nullptr;   // 2L + 6
+    double* pose_err = nullptr; // [B][4]: squared pose error vs the simulated truth + NEES
+    int last_tick = -1;        // last tick of the resident trace that nuslam_batch_run applied
     double Q[9], R[4];
     // resident trace
     double* tr_tw = nullptr; double* tr_mx = nullptr; double* tr_my = nullptr; int* tr_ids = nullptr;
@@ -418,7 +420,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -458,7 +460,8 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
         HIPCHK(hipMalloc(&h->cur_id, sizeof(int) * B));
         HIPCHK(hipMalloc(&h->akey, sizeof(int) * 2 * B));
         HIPCHK(hipMalloc(&h->tr, sizeof(double) * B));
-        HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 2)));
+        HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 6)));
+        HIPCHK(hipMalloc(&h->pose_err, sizeof(double) * 4 * B));
         HIPCHK(hipMemsetAsync(h->cur_id, 0, sizeof(int) * B, h->stream));
         HIPCHK(hipEventCreate(&h->t0));
         HIPCHK(hipEventCreate(&h->t1));
@@ -473,29 +476,29 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
 {
     memcpy(h->Q, Q, sizeof(h->Q));
     memcpy(h->R, R, sizeof(h->R));
-    double* d_robot = nullptr;
-    double* d_map = nullptr;
+    struct Staged {                                   // freed on every exit path, after the stream has drained
+        double* robot = nullptr; double* map = nullptr; hipStream_t stream;
+        ~Staged() { (void)hipStreamSynchronize(stream); if (robot) (void)hipFree(robot); if (map) (void)hipFree(map); }
+    } st;
+    st.stream = h->stream;
     HIPCHK(hipSetDevice(h->device));
     if (robot) {
-        HIPCHK(hipMalloc(&d_robot, sizeof(double) * 3 * h->B));
-        HIPCHK(hipMemcpyAsync(d_robot, robot, sizeof(double) * 3 * h->B, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMalloc(&st.robot, sizeof(double) * 3 * h->B));
+        HIPCHK(hipMemcpyAsync(st.robot, robot, sizeof(double) * 3 * h->B, hipMemcpyHostToDevice, h->stream));
     }
     if (map && h->n > 0) {
-        HIPCHK(hipMalloc(&d_map, sizeof(double) * 2 * h->n * (size_t)h->B));
-        HIPCHK(hipMemcpyAsync(d_map, map, sizeof(double) * 2 * h->n * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMalloc(&st.map, sizeof(double) * 2 * h->n * (size_t)h->B));
+        HIPCHK(hipMemcpyAsync(st.map, map, sizeof(double) * 2 * h->n * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHK(hipMemsetAsync(h->Pbuf[0], 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
     HIPCHK(hipMemsetAsync(h->Pbuf[1], 0, h->esize() * (size_t)h->B * h->p_stride, h->stream));
     View v = h->view();
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, -1, k_init<T>, grid, block, v, (const double*)d_robot, (const double*)d_map, (T*)h->P(),
+    DISPATCH_T(h, rc = launch(h, -1, k_init<T>, grid, block, v, (const double*)st.robot, (const double*)st.map, (T*)h->P(),
                               h->state[0], h->state[1], h->ctrl[0], h->ctrl[1]));
-    hipError_t e = hipStreamSynchronize(h->stream);
-    if (d_robot) (void)hipFree(d_robot);
-    if (d_map) (void)hipFree(d_map);
     if (rc) return rc;
-    HIPCHK(e);
+    HIPCHK(hipStreamSynchronize(h->stream));
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
     h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
     return NUSLAM_OK;
@@ -584,6 +587,24 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     return NUSLAM_OK;
 }
 
+// the statistics vector of nuslam_batch_stats into h->stats (device), on the handle's stream
+int launch_stats(nuslam_batch* h)
+{
+    { int frc = flush_pending(h); if (frc) return frc; }
+    View v = h->view();
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P(), h->tr));
+    if (rc) return rc;
+    // truth of the last tick applied from a generated trace (tube_world's own robot); absent otherwise
+    const bool have_truth = h->tr_truth != nullptr && h->last_tick >= 0 && h->last_tick < h->tr_ticks;
+    DISPATCH_T(h, rc = launch(h, -1, k_pose_error<T>, dim3((h->B + 63) / 64), dim3(64), v, (const T*)h->P(),
+                              (const double*)h->state[h->sidx], (const double*)(have_truth ? h->tr_truth : nullptr),
+                              (long long)h->tr_ticks * 3, (long long)h->last_tick * 3, h->pose_err));
+    if (rc) return rc;
+    return launch(h, -1, k_stats, dim3((h->L + 255) / 256), dim3(256), v, (const double*)h->state[h->sidx],
+                  (const double*)h->tr, (const double*)h->pose_err, h->stats);
+}
+
 // latched device status -> return code of a synchronising call
 int sync_status(nuslam_batch* h)
 {
@@ -625,6 +646,7 @@ const char* nuslam_strerror(int status)
     case NUSLAM_E_HIP: return "HIP runtime error";
     case NUSLAM_E_NODEV: return "no HIP device";
     case NUSLAM_E_NOMEM: return "out of memory";
+    case NUSLAM_E_CAPACITY: return "a fixed-size device table is too small for this input";
     default: return "unknown status";
     }
 }
@@ -731,6 +753,7 @@ void free_trace(nuslam_batch* h)
         if (p) (void)hipFree(p);
     h->tr_tw = h->tr_mx = h->tr_my = h->tr_truth = nullptr; h->tr_ids = nullptr; h->tr_scan = nullptr;
     h->tr_ticks = h->tr_m = h->tr_bcast = 0;
+    h->last_tick = -1;
     h->tr_presence_only = false;
     h->h_ids.clear();
     h->h_ids_pf.clear();
@@ -760,15 +783,10 @@ int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned 
     return NUSLAM_OK;
 }
 
-int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
-                          const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
-                          int known_ids, long long* empty_slots)
+static int simulate_into_trace(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
+                               const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
+                               int known_ids, long long* empty_slots)
 {
-    if (!h || !p || !landmarks || !cmd || n_world < 1 || n_world > kSimMaxWorld || ticks < 1 || m < 1)
-        return NUSLAM_E_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    free_trace(h);
     const size_t B = (size_t)h->B, T = (size_t)ticks, M = (size_t)m;
     struct Scratch {                                  // inputs of the two generator kernels; freed on every exit path
         double* lm = nullptr; double* cmd = nullptr; unsigned long long* empty = nullptr;
@@ -798,15 +816,16 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (p->lidar != 0.0) {
         // markers from the simulated lidar through the landmarks node's chain; they carry no identity
-        if (known_ids) { free_trace(h); return NUSLAM_E_ARG; }
+        if (known_ids) return NUSLAM_E_ARG;
         HIPCHK(hipMalloc(&h->tr_scan, sizeof(float) * B * T * 360));
         hipLaunchKernelGGL(k_sim_scan, dim3(ticks, h->B), dim3(256), 0, h->stream, a, h->tr_scan);
         HIPCHK(hipGetLastError());
-        int overflow = 0;
+        int overflow[2] = { 0, 0 };
         const int src = scan_to_markers(h->stream, h->tr_scan, (int)(B * T), p->lidar_min_range, p->lidar_max_range, m,
-                                        h->tr_mx, h->tr_my, h->tr_ids, d.empty, &overflow);
+                                        h->tr_mx, h->tr_my, h->tr_ids, d.empty, overflow);
         if (src) { g_hip_err = "scan_to_markers failed"; return src; }
-        if (overflow) { free_trace(h); return NUSLAM_E_ARG; }      // more markers in a scan than slots: raise m
+        if (overflow[0]) return NUSLAM_E_CAPACITY;                 // a scan with more clusters than the per-scan table holds
+        if (overflow[1]) return NUSLAM_E_ARG;                      // more accepted markers in a scan than slots: raise m
     } else {
         hipLaunchKernelGGL(k_sim_markers, dim3(ticks, h->B), dim3(256), lds, h->stream, a);
         HIPCHK(hipGetLastError());
@@ -824,6 +843,23 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
         HIPCHK(hipMemcpy(dst.data(), h->tr_ids, sizeof(int) * B * T * M, hipMemcpyDeviceToHost));
     }
     return NUSLAM_OK;
+}
+
+int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const double* landmarks, int n_world,
+                          const double* cmd, int ticks, int m, unsigned long long seed, unsigned first_filter,
+                          int known_ids, long long* empty_slots)
+{
+    if (!h || !p || !landmarks || !cmd || n_world < 1 || n_world > kSimMaxWorld || ticks < 1 || m < 1)
+        return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    free_trace(h);
+    const int rc = simulate_into_trace(h, p, landmarks, n_world, cmd, ticks, m, seed, first_filter, known_ids, empty_slots);
+    if (rc) {                                     // no half-made trace survives a failure, whatever step it came from
+        (void)hipStreamSynchronize(h->stream);
+        free_trace(h);
+    }
+    return rc;
 }
 
 int nuslam_batch_get_scan(nuslam_batch_t* h, int b, int tick, float out[360])
@@ -900,6 +936,7 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
                      (long long)h->tr_ticks * h->tr_m);
     }
     h->id_log = saved_log;
+    if (!rc && t_end > t_begin) h->last_tick = t_end - 1;
     return rc;
 }
 
@@ -946,18 +983,12 @@ int nuslam_batch_status(nuslam_batch_t* h, int clear, int* first_bad_filter, int
 
 int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len)
 {
-    if (!h || !out || out_len < 2 * h->L + 2) return NUSLAM_E_ARG;
+    if (!h || !out || out_len < 2 * h->L + 6) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
-    { int frc = flush_pending(h); if (frc) return frc; }
-    View v = h->view();
-    int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = launch(h, -1, k_trace<T>, dim3(h->B), dim3(256), v, (const T*)h->P(), h->tr));
-    if (rc) return rc;
-    rc = launch(h, -1, k_stats, dim3((h->L + 255) / 256), dim3(256), v, (const double*)h->state[h->sidx],
-                (const double*)h->tr, h->stats);
+    int rc = launch_stats(h);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out, h->stats, sizeof(double) * (2 * h->L + 2), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out, h->stats, sizeof(double) * (2 * h->L + 6), hipMemcpyDeviceToHost));
     return NUSLAM_OK;
 }
 
@@ -1059,6 +1090,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
 {
     if (!src || !out) return NUSLAM_E_ARG;
     nuslam_batch* s = src->core;
+    HIPCHK(hipSetDevice(s->device));              // before the flush: it launches on s->stream
     { int frc = flush_pending(s); if (frc) return frc; }
     nuslam_batch* d = nullptr;
     int rc = alloc_batch(1, s->n, s->dtype, s->device, &d);

@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_hip.so")   # override: A/B experiments only
 
-OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM = range(7)
+OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY = range(8)
 F64, F32 = 0, 1
 K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2 = range(7)
 
@@ -326,7 +326,8 @@ class Batch:
         return bad.value, st.value
 
     def stats(self):
-        out = np.zeros(2 * self.len + 2)
+        """{sum state (len), sum state^2 (len), sum pose error^2 (3), sum NEES, sum trace(P), count}: 2 len + 6."""
+        out = np.zeros(2 * self.len + 6)
         _chk(lib().nuslam_batch_stats(self._h, _p(out), out.size), "batch_stats")
         return out
 

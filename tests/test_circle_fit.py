@@ -159,3 +159,72 @@ def test_cpp_host_mirror_of_circle_fit(hip):
     m = next(r for r in rows if r[0] == "M")
     st, x, y, rad = O.circle_fit(*ref[0])
     assert abs(float(m[2]) - x) < 1e-9 and abs(float(m[4]) - 2 * rad) < 1e-9      # scale.x is the diameter (:124)
+
+
+def _ragged_scan(seed):
+    """A 360-ray scan with everything the cluster walk reacts to: out-of-range rays inside runs, runs of one and two
+    rays (discarded, and exempting their successor), a run through the 359 -> 0 seam, jumps right at the 0.04 gap."""
+    rng = np.random.default_rng(seed)
+    r = np.full(360, 2.0, dtype=np.float32)
+    a = int(rng.integers(0, 20))
+    while a < 360:
+        n = int(rng.choice([1, 1, 2, 2, 3, 4, 7, 15, 30]))
+        base = rng.uniform(0.06, 0.98)
+        seg = base + np.cumsum(rng.choice([0.0, 0.01, -0.01, 0.039, 0.041, -0.05], size=n, p=[.5, .2, .2, .04, .03, .03]))
+        hi = min(360, a + n)
+        r[a:hi] = seg[:hi - a].astype(np.float32)
+        a = hi + int(rng.choice([0, 0, 1, 1, 2, 5, 12]))
+    if seed % 3 == 0:
+        r[355:360] = 0.5; r[0:4] = 0.5          # a tube across the seam
+    if seed % 5 == 0:
+        r[rng.integers(0, 360, size=6)] = 1.2   # out-of-range rays dropped into runs
+    return r
+
+
+def test_host_cluster_points_matches_oracle_on_ragged_scans():
+    """cpp/nuslam/circle_fit_library.hpp::clusterPoints (index spans) against the oracle's restatement of the
+    reference walk (circle_fit_library.cpp:136-206), point for point, incl. the wrap-around and erase-loop quirks."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "shermbot-navigation_amd", "cpp", "tests", "fit_scan")
+    assert os.path.exists(exe), "build it first: make -C shermbot-navigation_amd/cpp"
+    scans = [_ragged_scan(s) for s in range(60)]
+    scans.append(np.full(360, 2.0, dtype=np.float32))                  # nothing in range
+    scans.append(np.full(360, 0.5, dtype=np.float32))                  # one run that never closes: everything is lost
+    txt = "\n".join(" ".join("%.9g" % x for x in sc) for sc in scans) + "\n"
+    out = subprocess.run([exe, "--clusters"], input=txt, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split("\n")
+    pos, small_seen, wrap_seen = 0, 0, 0
+    for sc in scans:
+        ref = O.cluster_points(sc, 0.05, 1.0)
+        assert lines[pos].split() == ["S", str(len(ref))], (lines[pos], len(ref))
+        pos += 1
+        for xs, ys in ref:
+            k = lines[pos].split(); pos += 1
+            assert k[0] == "K" and int(k[1]) == len(xs)
+            small_seen += len(xs) < 3
+            got = np.array([[float(v) for v in lines[pos + i].split()] for i in range(len(xs))]).reshape(-1, 2)
+            pos += len(xs)
+            assert np.array_equal(got[:, 0], xs) and np.array_equal(got[:, 1], ys)
+            wrap_seen += len(xs) > 0 and abs(np.arctan2(ys[-1], xs[-1]) + np.deg2rad(1)) < 1e-6
+    assert small_seen > 0 and wrap_seen > 0, "the scans must exercise the exempted small clusters and the seam"
+
+
+def test_classify_degenerate_clusters_oracle():
+    """1- and 2-point clusters survive clusterPoints' erase loop; the reference's classifyCluster then divides 0 by
+    angles.size() == 0: NaN, not a circle (circle_fit_library.cpp:236-249)."""
+    for n in (1, 2):
+        ok, sd = O.classify_cluster(np.arange(n) * 0.01 + 0.3, np.zeros(n) + 0.1)
+        assert not ok and np.isnan(sd)
+
+
+@pytest.mark.gpu
+def test_classify_degenerate_clusters_gpu(hip):
+    cl = [(np.array([0.3]), np.array([0.1])), (np.array([0.3, 0.31]), np.array([0.1, 0.1])),
+          arc(0.5, 0.2, 0.04, 0.3, 2.8, 12)]
+    out = hip.circle_fit_batch(cl)
+    assert list(out["is_circle"]) == [False, False, True]
+    assert np.isnan(out["angle_std"][0]) and np.isnan(out["angle_std"][1])
+    assert list(out["status"][:2]) == [1, 1]                       # circleFit: fewer than four points
