@@ -8,20 +8,31 @@ Workloads
   ekf1000   (default; BASELINE configs[1]) one EKF per GPU, N = 1000 landmarks, fp64 covariance, m = 16,
             known association; the map is initialised (one update per landmark) before the timed region.
             With --gpus N every rank runs its own independent replica (Monte-Carlo trials): weak scaling.
-  batch     (BASELINE configs[3]) --filters independent EKFs of N = 200 landmarks per GPU, one launch per
-            kernel for the whole batch.
+  batch     (BASELINE configs[3]) 1024 independent EKFs of N = 200 landmarks split over the ranks in contiguous
+            blocks (nuslam_hip.dist.shard; --filters F: F filters per GPU instead), one launch per kernel for a
+            rank's whole block; no collective in the data path, one RCCL all-gather of the statistics vector.
   da1000    (BASELINE configs[4]) as ekf1000 with unknown data association (associateLandmark per marker).
   ekf5000   (BASELINE configs[2]) one EKF, N = 5000, fp32 covariance, every predict propagates P with a resident
             dense Jacobian on the matrix cores (F P F^T, 4 L^3 flop) -- the MFMA-bound configuration.
-`value` = corrections (EKF updates) per second over all ranks = ranks * filters * m * steps / seconds.
+`value` = corrections (EKF updates) per second over all ranks.
 
-Extra objects: "roofline" for the dominant kernel (k_update; algorithmic bytes 2*L^2*w per launch per
-filter, duration from per-dispatch HIP events on the handle's stream) and "cpu_baseline" (the oracle's dense
-mode = the reference's algebra, timed on this host's cores on a bounded sample of the same workload).
+Timing: W untimed warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides and maxed over ranks.  One block at N = 1000 is only K x 0.1 ms, so the block is repeated (on fresh ticks of the
+same resident trace) until the timed blocks add up to >= 100 ms; `ms_per_step` is the MEDIAN block / K and the spread is
+reported beside it.
+
+Launch: `python bench.py --gpus N` starts N ranks itself (fresh child processes, started before this process touches
+the GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks already exist
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) and are used as they are.
+
+Extra objects: "roofline" for the dominant kernel (duration from per-dispatch HIP events on the handle's stream) and
+"cpu_baseline" (the reference's dense algebra timed on this host's cores on a bounded sample of the same workload).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,9 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+TARGET_TIMED_S = 0.100  # the timed blocks must add up to at least this
+MAX_BLOCKS = 400
+# rough step times (ms) only to size the resident trace; the number of blocks actually run is decided by the clock
+STEP_MS_GUESS = {"ekf1000": 0.05, "da1000": 0.1, "batch": 2.0, "ekf5000": 20.0}
 
 
 def parse():
@@ -41,7 +54,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ekf1000", choices=["ekf1000", "batch", "da1000", "ekf5000"])
     ap.add_argument("--landmarks", type=int, default=None)
-    ap.add_argument("--filters", type=int, default=None, help="filters per GPU (batch workload; default 1024/gpus)")
+    ap.add_argument("--filters", type=int, default=None, help="batch workload: filters PER GPU (weak scaling); default: "
+                                                              "--filters-total split over the ranks (strong scaling)")
+    ap.add_argument("--filters-total", type=int, default=1024, help="batch workload: filters over all ranks")
     ap.add_argument("--m", type=int, default=16, help="corrections per tick")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (0 = skip)")
@@ -49,18 +64,61 @@ def parse():
                     help="opt-in deferred application: a tick's corrections are kept as rank-2 factors and applied to P "
                          "once per tick (csrc/ekf_deferred.h); results agree with the default to rounding, not bitwise")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for the batch reduction (nccl = RCCL over xGMI; gloo only to rehearse "
-                         "the multi-rank path on one GPU)")
+                    help="torch.distributed backend for barriers / max-over-ranks (nccl = RCCL over xGMI; gloo only to "
+                         "rehearse the multi-rank path with several ranks on one GPU)")
     ap.add_argument("--trace", default=None, choices=["host", "device"],
                     help="batch workload: per-filter Monte-Carlo traces generated on the device by the simulator kernels "
                          "(default), or one host-made trace per rank replayed by every filter")
     ap.add_argument("--no-pairing", action="store_true", help="one k_update launch per correction (disable k_update2)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
+    ap.add_argument("--min-timed-ms", type=float, default=1e3 * TARGET_TIMED_S)
+    ap.add_argument("--blocks", type=int, default=0, help="run exactly this many timed K-step blocks (0: until --min-timed-ms)")
     ap.add_argument("--events-in-timed-region", action="store_true",
-                    help="attach the per-dispatch HIP events inside the timed region itself (costs ~25%% throughput: "
-                         "every dispatch then carries a completion signal); default: a second pass of K identical steps "
-                         "right after the timed one")
+                    help="attach the per-dispatch HIP events inside the timed region itself (costs throughput: every "
+                         "dispatch then carries a completion signal); default: one more block of K steps right after")
+    ap.add_argument("--dump", default=None, help="batch workload: write every local filter's final state / seen and the "
+                                                 "reduced statistics to this .npz (rank suffix added) -- for the sharding test")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no rank environment: start N fresh rank processes (this process has not touched
+    the GPU and never will), wait, relay rank 0's line.  Children are started, never exec'd into."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()            # counts devices without initialising the GPU (safe before a spawn)
+    if args.backend == "nccl" and ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one GPU per rank; use --backend gloo "
+                         "to rehearse several ranks on one GPU)\n" % (args.gpus, ndev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(n, m, tr, budget_s, warm_state):
@@ -70,6 +128,7 @@ def cpu_baseline(n, m, tr, budget_s, warm_state):
       oracle-c    oracle/nuslam_oracle.c dense mode, OpenMP-blocked loops
       numpy-blas  tests/_np_ekf.py, the same chain through numpy's BLAS dgemm (OpenBLAS) -- what Armadillo itself
                   would dispatch to."""
+    import numpy as np
     import _oracle as O
     import _np_ekf
     from nuslam_hip import synth
@@ -104,23 +163,42 @@ def cpu_baseline(n, m, tr, budget_s, warm_state):
         done += 1
     dt = time.perf_counter() - t0
     cands["numpy-blas"] = (done * m / dt, done, dt)
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
+    if limiter is not None and hasattr(limiter, "unregister"):
+        limiter.unregister()
 
     best = max(cands, key=lambda k: cands[k][0])
     v, done, dt = cands[best]
-    return {"value": v, "unit": "updates/s", "cores": cores, "kind": "port", "impl": best,
+    return {"value": v, "unit": "updates/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port", "impl": best,
             "sample": "%d tick(s) (1 predict + %d updates each) of the same N=%d trace from the same post-initialisation "
                       "snapshot, reference algebra (two L^3 GEMMs per predict, one per update), %.1f s; faster of "
                       "{oracle-c: %.2f, numpy-blas: %.2f} updates/s" % (done, m, n, dt, cands["oracle-c"][0], cands["numpy-blas"][0]),
             "ms_per_step": 1e3 * dt / done}, o, cands["oracle-c"][1]
 
 
+def pmc_traffic(nh, sweep_kernel_sig):
+    """HBM bytes per launch from a committed rocprofv3 --pmc measurement (profiles/r*/**pmc_hbm*.json made by
+    tools/summarize_pmc.py), quoted ONLY when that record was taken from the very kernel sources the loaded library
+    was built from (nuslam_build_info) and names the kernel instantiation this run's launches used; otherwise null."""
+    import glob
+    have = nh.build_info()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_hbm*.json")), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("build_info") == have and sweep_kernel_sig in rec.get("kernel_name", ""):
+            return rec["per_launch_bytes"]["hbm_traffic"], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import numpy as np
     import torch
     import torch.distributed as dist
     if world > 1:
@@ -134,33 +212,51 @@ def main():
     ndev = torch.cuda.device_count()
     dev = (local_rank % max(ndev, 1)) if world > 1 else 0
     coll_dev = "cuda" if args.backend == "nccl" else None
+    ranks_seen = dist.get_world_size() if world > 1 else 1
 
     import nuslam_hip as nh
     from nuslam_hip import synth
+    from nuslam_hip import dist as nd
 
     if args.workload == "ekf5000":
         args.dtype = "f32"
         if args.steps == 200 and args.warmup == 20:
-            args.steps, args.warmup = 5, 1          # a tick is ~45 ms here
+            args.steps, args.warmup = 5, 1          # a tick is ~35 ms here
     dtype = nh.F64 if args.dtype == "f64" else nh.F32
     w = 8 if dtype == nh.F64 else 4
+    first_filter = 0
     if args.workload == "batch":
         n = args.landmarks or 200
-        B = args.filters or max(1, 1024 // world)
+        if args.filters:
+            B, first_filter, filters_total = args.filters, rank * args.filters, world * args.filters
+        else:
+            first_filter, B = nd.shard(args.filters_total, world, rank)      # contiguous blocks, remainders included
+            filters_total = args.filters_total
+        if B < 1:
+            raise SystemExit("bench.py: rank %d would own no filter (%d filters over %d ranks)" % (rank, filters_total, world))
     else:
         n = args.landmarks or (5000 if args.workload == "ekf5000" else 1000)
-        B = 1
+        B, filters_total = 1, world
     m = min(args.m, n)
     L = 3 + 2 * n
     K, W = args.steps, args.warmup
     known = args.workload != "da1000"
 
+    # how many K-step blocks the resident trace must hold: enough for >= the timed target even if the code were several
+    # times faster than today, plus one block for the kernel-event pass
+    blocks_cap = int(min(MAX_BLOCKS, max(1, np.ceil(args.min_timed_ms / (K * STEP_MS_GUESS[args.workload] * (B / 1024.0 if args.workload == "batch" else 1.0))))))
+    if args.blocks > 0:
+        blocks_cap = args.blocks
+    ticks_total = W + K * (blocks_cap + 1)
+
     # ---- synthetic input (seeded; Monte-Carlo replica r uses seed 12345 + r), made resident in HBM
-    seed = 12345 + rank
+    seed = 12345 if args.workload == "batch" else 12345 + rank      # the batch is ONE world split over the ranks
     # data association needs one free slot: associateLandmark writes a hypothetical landmark at index seen+1 and
     # indexes out of bounds on a full map (slam_library.cpp:206-207), so the world holds n-1 landmarks there
     n_world = n if known else n - 1
-    tr = synth.make_trace(n_world, W + 3 * K, m, seed=seed, noise_sigma=None if known else 1e-4)
+    trace_kind = args.trace or ("device" if args.workload == "batch" else "host")
+    host_ticks = ticks_total if trace_kind == "host" else 4
+    tr = synth.make_trace(n_world, host_ticks, m, seed=seed, noise_sigma=None if known else 1e-4)
     # association only matches when the innovation is ~100x below sqrt(R) (threshold 0.01, slam_library.cpp:193,238),
     # so that workload measures with 1e-4 m marker noise, in the map-initialising pass too
     bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed, noise_sigma=None if known else 1e-4)
@@ -172,7 +268,7 @@ def main():
         # well-conditioned Q = diag(1e-4) of SURVEY section 8d so that matches (and corrections) actually happen.
         Q = np.diag([1e-4, 1e-4, 1e-4])
 
-    if B == 1:
+    if B == 1 and args.workload != "batch":
         ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
         bt = ekf.as_batch()
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
@@ -199,19 +295,18 @@ def main():
         bt.sync()
         warm_state = None
     ids = tr.ids if known else None
-    trace_kind = args.trace or ("device" if args.workload == "batch" else "host")
     if trace_kind == "device":
         # every filter is its own Monte-Carlo trial -- its trace is generated in HBM by the simulator
         # kernels (tube_world.cpp:509-533 per filter) from the random streams of its GLOBAL filter index, so the
         # sharded run reproduces the unsharded one and nothing but the six-number parameter block crosses PCIe
-        ticks_total = W + 3 * K
         uL, uR = 0.30 * 50, 0.36 * 50                      # the wheel increments of synth.make_trace, per second
         cmd = np.zeros((ticks_total, 2))
         cmd[:, 0] = (synth.WHEEL_RADIUS / synth.WHEEL_BASE) * (uR - uL)
         cmd[:, 1] = (synth.WHEEL_RADIUS / 2) * (uL + uR)
         cmd[24::25, 0] = 0.0                               # every 25th tick straight: the dth == 0 branch
         sim = nh.SimParams(marker_sigma=float(np.sqrt(1e-3)) if known else 1e-4, max_range=0.0)
-        bt.simulate(sim, tr.landmarks, cmd, m, 12345, first_filter=rank * B, known_ids=known)
+        world_lm = synth.make_landmarks(n_world, 12345)    # ONE world for all ranks: only the noise streams differ
+        bt.simulate(sim, world_lm, cmd, m, 12345, first_filter=first_filter, known_ids=known)
     else:
         bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
     if args.deferred:
@@ -231,20 +326,26 @@ def main():
     barrier()
     in_region = args.events_in_timed_region
     bt.profile(in_region)
-    t0 = time.perf_counter()
-    bt.run(W, W + K)                   # EXACTLY K timed steps
-    bt.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    block_s = []
+    t_at = W
+    while len(block_s) < blocks_cap:
+        barrier()
+        t0 = time.perf_counter()
+        bt.run(t_at, t_at + K)         # EXACTLY K timed steps
+        bt.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        block_s.append(time.perf_counter() - t0)
+        t_at += K
+        if world == 1 and args.blocks == 0 and sum(block_s) >= 1e-3 * args.min_timed_ms:
+            break                      # (with several ranks every rank runs the same, precomputed number of blocks)
     if not in_region:
         # kernel durations: the next K steps of the same trace, every dispatch bracketed by its own HIP events
         # on the handle's stream (hipExtLaunchKernelGGL start/stop events)
         bt.profile(True)
-        bt.run(W + K, W + 2 * K)
+        bt.run(t_at, t_at + K)
         bt.sync()
-    use_events = True
     sweep_ms, sweep_n = bt.profile_read(nh.K_UPDATE)
     pair_ms, pair_n = bt.profile_read(nh.K_UPDATE2)
     pred_ms, pred_n = bt.profile_read(nh.K_PREDICT)
@@ -253,47 +354,61 @@ def main():
     dupd_ms, dupd_n = bt.profile_read(nh.K_UPDATE_DEFERRED)
     flush_ms, flush_n = bt.profile_read(nh.K_FLUSH)
     bt.profile(False)
-    deferred_extra = None
-    if args.workload == "ekf1000" and not args.deferred and not in_region and K >= 4:
-        # the same K steps once more with the opt-in deferred application (reported beside the headline, never as it)
-        bt.set_deferred(True)
-        bt.run(W + 2 * K, W + 2 * K + 2)
-        barrier()
-        td = time.perf_counter()
-        bt.run(W + 2 * K + 2, W + 3 * K)
-        bt.sync()
-        td = time.perf_counter() - td
-        bt.set_deferred(False)
-        deferred_extra = {"value": float(world) * B * m * (K - 2) / td, "unit": "updates/s", "ms_per_step": 1e3 * td / (K - 2),
-                          "note": "opt-in mode (nuslam_ekf_set_deferred): a tick's corrections kept as rank-2 factors, P rewritten "
-                                  "once per tick; agrees with the default path to rounding (tests/test_gpu_deferred.py), not bitwise"}
     bad, st = bt.status()
     if st != 0:
         raise RuntimeError("device status %d on filter %d" % (st, bad))
 
-    from nuslam_hip import dist as nd
+    block_s = np.array(block_s)
+    rccl = None
     if world > 1:
-        dt = nd.max_over_ranks(dt, device=coll_dev)
-        # the batch reduction over xGMI (RCCL): Monte-Carlo statistics of all trials, gathered and summed in rank order
-        total, _ = nd.reduce_stats(bt.stats(), device=coll_dev)
-        n_filters_total = int(total[-1])
+        # per-block max over ranks
+        t = torch.tensor(block_s, dtype=torch.float64)
+        if coll_dev:
+            t = t.to(coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        block_s = t.cpu().numpy()
+        # the batch reduction: Monte-Carlo statistics of all trials, gathered and summed in rank order -- once through
+        # torch.distributed (backend as given), and, with one GPU per rank, through the library's own C-ABI RCCL path
+        local_stats = bt.stats()
+        total, per_rank = nd.reduce_stats(local_stats, device=coll_dev)
+        n_filters_seen = int(total[-1])
+        if args.backend == "nccl":
+            try:
+                uid = [nh.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = nh.Comm(uid[0], world, rank, dev)
+                tot2, rows2 = bt.reduce_stats(comm)
+                rccl = {"c_abi_allgather": "ok", "ranks": comm.world,
+                        "equals_torch_distributed_bitwise": bool(np.array_equal(tot2, total) and np.array_equal(rows2, per_rank))}
+                comm.close()
+            except Exception as e:      # reported in the line, never hidden: the torch.distributed result above stands
+                rccl = {"c_abi_allgather": "failed", "error": str(e)[:300]}
     else:
-        n_filters_total = B
+        local_stats = bt.stats()
+        total, per_rank = local_stats, local_stats[None, :]
+        n_filters_seen = int(total[-1])
+
+    if args.dump:
+        states = np.stack([bt.state(b) for b in range(B)])
+        seens = np.array([bt.seen(b) for b in range(B)])
+        np.savez(args.dump + ".rank%d.npz" % rank, first_filter=first_filter, states=states, seens=seens,
+                 local_stats=local_stats, total=total, per_rank=per_rank)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    updates = float(world) * B * m * K
+    dt_med = float(np.median(block_s))
+    updates_per_block = float(filters_total if args.workload == "batch" else world) * m * K
     out = {
         "metric": "EKF updates/sec (predict+correct, N landmarks)",
-        "value": updates / dt,
+        "value": updates_per_block / dt_med,
         "unit": "updates/s",
         "n_gpus": world,
         "steps": K,
         "warmup": W,
-        "ms_per_step": 1e3 * dt / K,
+        "ms_per_step": 1e3 * dt_med / K,
         "higher_is_better": True,
         # single filter: one replica per GPU (per-GPU work fixed -> weak); batch without --filters: 1024 filters split
         # over the ranks (total work fixed -> strong); batch with --filters F: F filters per GPU (weak)
@@ -302,60 +417,69 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": {"ekf1000": "single EKF per GPU, known association (BASELINE configs[1])",
-                                "batch": "batch of independent EKFs per GPU (BASELINE configs[3])",
+                                "batch": "batch of independent EKFs sharded over the GPUs (BASELINE configs[3])",
                                 "da1000": "single EKF per GPU, unknown data association (BASELINE configs[4])",
                                 "ekf5000": "single EKF per GPU, fp32, dense MFMA F P F^T predict (BASELINE configs[2])"}[args.workload],
-                   "landmarks": n, "state_len": L, "filters_per_gpu": B, "filters_total": n_filters_total,
-                   "updates_per_step": m, "parallelism": "replicas x%d" % world if B == 1 else "filters sharded x%d" % world,
+                   "landmarks": n, "state_len": L, "filters_rank0": B, "filters_total": filters_total,
+                   "filters_counted_by_reduction": n_filters_seen,
+                   "updates_per_step": m, "parallelism": "replicas x%d" % world if args.workload != "batch" else "filters sharded x%d" % world,
+                   "ranks_seen_by_backend": ranks_seen, "backend": (args.backend if world > 1 else None),
                    "trace": "per-filter, generated on the device (k_sim_path / k_sim_markers)" if trace_kind == "device"
                             else "one host-made trace per rank, resident in HBM",
                    "kernel_events_in_timed_region": in_region, "Q_diag": float(Q[0, 0]), "R_diag": float(R[0, 0])},
-        "ticks_per_s": float(world) * B * K / dt,
+        "timing": {"blocks": int(block_s.size), "steps_per_block": K, "timed_region_ms": 1e3 * float(block_s.sum()),
+                   "ms_per_step_median": 1e3 * dt_med / K, "ms_per_step_min": 1e3 * float(block_s.min()) / K,
+                   "ms_per_step_max": 1e3 * float(block_s.max()) / K,
+                   "ms_per_step_stdev": 1e3 * (statistics.pstdev(block_s.tolist()) if block_s.size > 1 else 0.0) / K,
+                   "note": "each block = exactly K steps bracketed by barrier + synchronize, max over ranks; value and "
+                           "ms_per_step are the median block"},
+        "ticks_per_s": float(filters_total if args.workload == "batch" else world) * K / dt_med,
+        "build_info": nh.build_info(),
     }
+    if rccl is not None:
+        out["rccl"] = rccl
+    if args.workload == "batch":
+        out["batch_stats"] = {"mean_sq_pose_error_th_x_y": (total[2 * L:2 * L + 3] / max(n_filters_seen, 1)).tolist(),
+                              "mean_nees": float(total[2 * L + 3] / max(n_filters_seen, 1)),
+                              "mean_trace_P": float(total[2 * L + 4] / max(n_filters_seen, 1))}
     sweep_kernel, units = "k_update", 1
-    if use_events and pair_n > sweep_n:
+    if pair_n > sweep_n:
         # most corrections went through k_update2: TWO corrections per pass over P (bit-identical to two k_update)
         sweep_ms, sweep_n, sweep_kernel, units = pair_ms, pair_n, "k_update2", 2
-    if use_events and sweep_n:
-        # the algorithmic figure is 2*L^2*w bytes per correction per filter (read + write every P entry
-        # once); `achieved` = that figure x the corrections one launch processes / the launch duration.  k_update2
-        # really moves half of it per correction (temporal blocking), which `actual_bytes_per_launch` and `traffic` show.
-        per_unit_bytes = 2.0 * L * L * w * B
-        per_launch_bytes = per_unit_bytes * units
+    if sweep_n:
+        # roofline.frac is PHYSICAL: the bytes one launch cannot avoid moving -- every element of P of every filter of
+        # the launch read once and written once, 2*L^2*w*B, however many corrections the launch fuses -- over the
+        # launch's measured duration, over the 8 TB/s HBM peak.  SURVEY 8(d)'s per-correction figure (2*L^2*w per
+        # correction x corrections per launch) is kept beside it as effective_*: it can exceed the peak for a launch
+        # that applies two corrections in one pass and is a throughput figure, not a roofline fraction.
+        min_bytes = 2.0 * L * L * w * B
         avg_s = 1e-3 * sweep_ms / sweep_n
-        ach = per_launch_bytes / avg_s / 1e9
-        # HBM bytes per launch from the PMC counters: a committed rocprofv3 --pmc measurement of this very workload
-        # (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 correction); null for others
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "ekf1000_pmc_hbm_traffic.json")
-        if args.workload == "ekf1000" and n == 1000 and dtype == nh.F64 and os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            if rec.get("kernel", "k_update") == sweep_kernel:
-                traffic = rec["per_launch_bytes"]["hbm_traffic"]
+        ach = min_bytes / avg_s / 1e9
+        tname = "double" if dtype == nh.F64 else "float"
+        traffic, traffic_src = pmc_traffic(nh, "%s<%s" % (sweep_kernel, tname))
         out["roofline"] = {"bound": "hbm", "kernel": sweep_kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": 1e6 * avg_s, "launches": sweep_n, "corrections_per_launch": units,
-                           "algorithmic_bytes_per_launch": per_launch_bytes,
-                           "actual_bytes_per_launch": per_unit_bytes,
-                           "achieved_actual_bytes": per_unit_bytes / avg_s / 1e9,
-                           "frac_actual_bytes": per_unit_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
-                           "note": "achieved/frac follow the algorithmic definition (2*L^2*w bytes per correction x "
-                                   "corrections per launch); a launch that applies two corrections in one pass moves each "
-                                   "byte once, so frac can exceed 1 -- achieved_actual_bytes / frac_actual_bytes / traffic "
-                                   "are what crosses the memory interface"}
+                           "min_bytes_per_launch": min_bytes,
+                           "effective_GBps": units * min_bytes / avg_s / 1e9,
+                           "effective_frac": units * min_bytes / avg_s / 1e9 / HBM_PEAK_GBS,
+                           "note": "achieved/frac: minimum bytes one launch must move (2*L^2*w*B: P read once, written once) / "
+                                   "launch duration (HIP events) / 8 TB/s.  effective_*: SURVEY 8(d)'s 2*L^2*w per CORRECTION x "
+                                   "corrections per launch -- a throughput figure that exceeds the physical one when a launch "
+                                   "fuses corrections.  traffic: FETCH_SIZE x2 + WRITE_SIZE from separate rocprofv3 --pmc passes "
+                                   "of this build (null when no record matches nuslam_build_info())"}
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
     if args.deferred and flush_n:
-        # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved);
-        # "effective" = the eager formula (2*L^2*w per correction) over the time actually spent per correction
+        # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved)
         per_launch_bytes = 2.0 * L * L * w * B
         avg_s = 1e-3 * flush_ms / flush_n
         ach = per_launch_bytes / avg_s / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_flush", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e6 * avg_s, "launches": flush_n,
-                           "algorithmic_bytes_per_launch": per_launch_bytes,
-                           "effective_GBps_eager_formula": per_launch_bytes * out["value"] / (world * B) / 1e9}
+                           "min_bytes_per_launch": per_launch_bytes,
+                           "effective_GBps": per_launch_bytes * out["value"] / (world * B) / 1e9}
         out["kernel_us"] = {"update_deferred": 1e3 * dupd_ms / max(dupd_n, 1), "flush": 1e3 * flush_ms / flush_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1)}
         out["config"]["deferred"] = True
@@ -367,14 +491,13 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "k_gemm (F P, then T F^T + Qbar)", "achieved": flop / avg_s / 1e12,
                            "peak": peak, "unit": "TFLOP/s", "frac": flop / avg_s / 1e12 / peak, "traffic": None,
                            "avg_launch_us": 1e6 * avg_s, "launches": gemm_n, "algorithmic_flop_per_launch": flop}
-        out["kernel_us"]["dense_gemm"] = 1e6 * avg_s
-    if deferred_extra is not None:
-        out["deferred_mode"] = deferred_extra
+        out.setdefault("kernel_us", {})["dense_gemm"] = 1e6 * avg_s
     if warm_state is not None and args.cpu_seconds > 0 and args.workload == "ekf1000":
-        ptr = synth.make_trace(n, W + 3 * K, m, seed=12345)
+        ptr = synth.make_trace(n, 64, m, seed=12345)
         cb, orc, orc_ticks = cpu_baseline(n, m, ptr, args.cpu_seconds, warm_state)
         out["cpu_baseline"] = cb
         out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
+        out["speedup_note"] = "GPU structured O(L^2) correction vs the reference's dense O(L^3) algebra on the host cores"
         # parity in the same run: the ticks the CPU oracle (dense reference algebra) just ran, replayed on the GPU from
         # the same post-initialisation snapshot through the same kernels the timed region used
         g2 = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
@@ -390,6 +513,7 @@ def main():
                          "rel_frobenius_cov": float(np.linalg.norm(gP - oP) / np.linalg.norm(oP)),
                          "seen_equal": bool(g2.seen == orc.seen), "tolerance": 1e-6}
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

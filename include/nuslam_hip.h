@@ -38,6 +38,7 @@ typedef enum {
     NUSLAM_E_HIP = 4,       /* a HIP runtime call failed; nuslam_last_hip_error() has the text */
     NUSLAM_E_NODEV = 5,     /* no HIP device available */
     NUSLAM_E_NOMEM = 6,
+    NUSLAM_E_COMM = 8,      /* RCCL could not be loaded or a collective failed; nuslam_last_hip_error() has the text */
     NUSLAM_E_CAPACITY = 7   /* a fixed-size device table is too small for this input (nuslam_batch_simulate with lidar:
                                a scan left more clusters than the per-scan table of 64 holds) */
 } nuslam_status;
@@ -50,6 +51,9 @@ typedef struct nuslam_batch nuslam_batch_t; /* B independent filters (Monte-Carl
 const char* nuslam_strerror(int status);
 const char* nuslam_last_hip_error(void);
 int nuslam_abi_version(void);
+/* "csrc=<16 hex digits>": a content hash of the kernel sources this library was built from (profiles/ records carry
+ * it so that a counter measurement is only ever quoted beside the code it was taken from) */
+const char* nuslam_build_info(void);
 int nuslam_device_count(int* count);
 
 /* ------------------------------------------------------------------ host-side helpers (pure functions) */
@@ -107,6 +111,9 @@ int nuslam_ekf_get_cov(nuslam_ekf_t* h, double* out, int ld);
 int nuslam_ekf_get_seen(nuslam_ekf_t* h, int* seen);
 /* overwrite (state, covariance, seen): checkpoint restore / warm-start fixtures */
 int nuslam_ekf_restore(nuslam_ekf_t* h, const double* state, const double* cov, int ld, int seen);
+/* checkpoint: state (len), covariance (column-major, leading dimension ld) and seen in one call -- the reference
+ * keeps these three members (slam_library.hpp:26-33); nuslam_ekf_restore takes them back.  Synchronises. */
+int nuslam_ekf_snapshot(nuslam_ekf_t* h, double* state, int len, double* cov, int ld, int* seen);
 int nuslam_ekf_sync(nuslam_ekf_t* h);
 /* latched device-side status (see Conventions); clear != 0 resets it */
 int nuslam_ekf_status(nuslam_ekf_t* h, int clear, int* status_out);
@@ -137,6 +144,19 @@ int nuslam_batch_status(nuslam_batch_t* h, int clear, int* first_bad_filter, int
  * robot's pose after the last tick nuslam_batch_run applied (traces made by nuslam_batch_simulate keep it); with any
  * other trace the four truth-dependent entries are 0. */
 int nuslam_batch_stats(nuslam_batch_t* h, double* out, int out_len);
+/* The batch reduction over RCCL / xGMI (one process per GPU, the filters sharded over the ranks, no
+ * collective in the data path).  Rank 0 makes an id and hands it to the other ranks by any channel the host program
+ * has (a file, MPI, torch.distributed ...); every rank then creates its communicator on its own device.
+ * nuslam_batch_reduce_stats: ncclAllGather of every rank's nuslam_batch_stats vector on the batch's stream, then
+ * the rows added in rank order on the device -- the same bits on every rank and for every ring order.  total gets
+ * 2*len + 6 doubles; per_rank (may be NULL) world x (2*len + 6).  Collective: every rank must call it. */
+#define NUSLAM_COMM_ID_BYTES 128
+typedef struct nuslam_comm nuslam_comm_t;
+int nuslam_comm_unique_id(unsigned char id[NUSLAM_COMM_ID_BYTES]);
+int nuslam_comm_create(const unsigned char id[NUSLAM_COMM_ID_BYTES], int world, int rank, int device, nuslam_comm_t** out);
+int nuslam_comm_destroy(nuslam_comm_t* c);
+int nuslam_comm_size(const nuslam_comm_t* c, int* world, int* rank);
+int nuslam_batch_reduce_stats(nuslam_batch_t* h, nuslam_comm_t* c, double* total, int total_len, double* per_rank);
 /* a one-filter view for the single-filter API above is the batch of size 1: */
 int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do not destroy */
 

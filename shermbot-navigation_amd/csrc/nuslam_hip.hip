@@ -7,6 +7,7 @@
 #include "ekf_kernels.h"
 #include "dense_predict.h"
 #include "ekf_sim.h"
+#include "build/build_info.h"
 
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -18,6 +19,8 @@
 #include <string>
 #include <utility>
 #include <vector>
+
+#include "ekf_comm.h"
 
 using namespace nuslam;
 
@@ -647,12 +650,14 @@ const char* nuslam_strerror(int status)
     case NUSLAM_E_NODEV: return "no HIP device";
     case NUSLAM_E_NOMEM: return "out of memory";
     case NUSLAM_E_CAPACITY: return "a fixed-size device table is too small for this input";
+    case NUSLAM_E_COMM: return "RCCL error; nuslam_last_hip_error() has the text";
     default: return "unknown status";
     }
 }
 
 const char* nuslam_last_hip_error(void) { return g_hip_err.c_str(); }
 int nuslam_abi_version(void) { return NUSLAM_HIP_ABI_VERSION; }
+const char* nuslam_build_info(void) { return "csrc=" NUSLAM_CSRC_HASH; }
 
 int nuslam_device_count(int* count)
 {
@@ -1264,6 +1269,108 @@ int nuslam_ekf_use_dense_predict(nuslam_ekf_t* h, int enable)
     if (enable && !h->core->f_staged) return NUSLAM_E_ARG;
     h->core->dense_predict = enable != 0;
     return NUSLAM_OK;
+}
+
+// ---- the batch reduction over RCCL / xGMI
+#define NCCLCHK(expr)                                                                                  \
+    do {                                                                                               \
+        nuslam_comm_detail::Result r__ = (expr);                                                       \
+        if (r__ != 0) {                                                                                \
+            g_hip_err = std::string(#expr) + ": " + nuslam_comm_detail::api().GetErrorString(r__);    \
+            return NUSLAM_E_COMM;                                                                      \
+        }                                                                                              \
+    } while (0)
+
+int nuslam_comm_unique_id(unsigned char id[NUSLAM_COMM_ID_BYTES])
+{
+    if (!id) return NUSLAM_E_ARG;
+    auto& a = nuslam_comm_detail::api();
+    if (!a.so) { g_hip_err = a.err; return NUSLAM_E_COMM; }
+    nuslam_comm_detail::UniqueId u;
+    NCCLCHK(a.GetUniqueId(&u));
+    memcpy(id, u.internal, NUSLAM_COMM_ID_BYTES);
+    return NUSLAM_OK;
+}
+
+int nuslam_comm_create(const unsigned char id[NUSLAM_COMM_ID_BYTES], int world, int rank, int device, nuslam_comm_t** out)
+{
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return NUSLAM_E_ARG;
+    auto& a = nuslam_comm_detail::api();
+    if (!a.so) { g_hip_err = a.err; return NUSLAM_E_COMM; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return NUSLAM_E_NODEV; }
+    if (device < 0 || device >= count) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    nuslam_comm* c = new (std::nothrow) nuslam_comm();
+    if (!c) return NUSLAM_E_NOMEM;
+    c->world = world; c->rank = rank; c->device = device;
+    nuslam_comm_detail::UniqueId u;
+    memcpy(u.internal, id, NUSLAM_COMM_ID_BYTES);
+    nuslam_comm_detail::Result r = a.CommInitRank(&c->comm, world, u, rank);
+    if (r != 0) {
+        g_hip_err = std::string("ncclCommInitRank: ") + a.GetErrorString(r);
+        delete c;
+        return NUSLAM_E_COMM;
+    }
+    *out = c;
+    return NUSLAM_OK;
+}
+
+int nuslam_comm_destroy(nuslam_comm_t* c)
+{
+    if (!c) return NUSLAM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->gathered) (void)hipFree(c->gathered);
+    if (c->total) (void)hipFree(c->total);
+    if (c->comm) (void)nuslam_comm_detail::api().CommDestroy(c->comm);
+    delete c;
+    return NUSLAM_OK;
+}
+
+int nuslam_comm_size(const nuslam_comm_t* c, int* world, int* rank)
+{
+    if (!c) return NUSLAM_E_ARG;
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_reduce_stats(nuslam_batch_t* h, nuslam_comm_t* c, double* total, int total_len, double* per_rank)
+{
+    if (!h || !c || !total || total_len < 2 * h->L + 6 || c->device != h->device) return NUSLAM_E_ARG;
+    const int len = 2 * h->L + 6;
+    HIPCHK(hipSetDevice(h->device));
+    if (c->cap < len) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (c->gathered) (void)hipFree(c->gathered);
+        if (c->total) (void)hipFree(c->total);
+        c->gathered = c->total = nullptr; c->cap = 0;
+        HIPCHK(hipMalloc(&c->gathered, sizeof(double) * (size_t)c->world * len));
+        HIPCHK(hipMalloc(&c->total, sizeof(double) * len));
+        c->cap = len;
+    }
+    int rc = launch_stats(h);                       // this rank's vector into h->stats, on the handle's stream
+    if (rc) return rc;
+    // every rank contributes `len` doubles; rank r's row lands at gathered + r * len on every rank
+    NCCLCHK(nuslam_comm_detail::api().AllGather(h->stats, c->gathered, (size_t)len, nuslam_comm_detail::kDouble, c->comm,
+                                                h->stream));
+    hipLaunchKernelGGL(nuslam_comm_detail::k_rank_ordered_sum, dim3((len + 255) / 256), dim3(256), 0, h->stream,
+                       (const double*)c->gathered, c->world, len, c->total);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(total, c->total, sizeof(double) * len, hipMemcpyDeviceToHost));
+    if (per_rank) HIPCHK(hipMemcpy(per_rank, c->gathered, sizeof(double) * (size_t)c->world * len, hipMemcpyDeviceToHost));
+    return NUSLAM_OK;
+}
+
+// getStateVector + getCovariance + getSeenLandmarks in one call: the checkpoint that nuslam_ekf_restore takes back
+int nuslam_ekf_snapshot(nuslam_ekf_t* h, double* state, int len, double* cov, int ld, int* seen)
+{
+    if (!h || !state || !cov || !seen) return NUSLAM_E_ARG;
+    int rc = get_state(h->core, 0, state, len);
+    if (!rc) rc = get_cov(h->core, 0, cov, ld);
+    if (!rc) rc = get_seen(h->core, 0, seen);
+    return rc;
 }
 
 } // extern "C"

@@ -13,7 +13,8 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_hip.so")   # override: A/B experiments only
 
-OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY = range(8)
+OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY, E_COMM = range(9)
+COMM_ID_BYTES = 128
 F64, F32 = 0, 1
 K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2 = range(7)
 
@@ -75,6 +76,13 @@ SYMBOLS = [
     ("nuslam_batch_get_trace", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip, _dp]),
     ("nuslam_batch_get_scan", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("nuslam_philox4x32_10", C.c_int, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
+    ("nuslam_build_info", C.c_char_p, []),
+    ("nuslam_ekf_snapshot", C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _ip]),
+    ("nuslam_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
+    ("nuslam_comm_create", C.c_int, [C.POINTER(C.c_ubyte), C.c_int, C.c_int, C.c_int, _vpp]),
+    ("nuslam_comm_destroy", C.c_int, [_vp]),
+    ("nuslam_comm_size", C.c_int, [_vp, _ip, _ip]),
+    ("nuslam_batch_reduce_stats", C.c_int, [_vp, _vp, _dp, C.c_int, _dp]),
 ]
 
 
@@ -114,7 +122,7 @@ class NuslamError(RuntimeError):
         try:
             L = lib()
             msg = "%s: %s" % (where, L.nuslam_strerror(code).decode())
-            if code == E_HIP:
+            if code in (E_HIP, E_COMM):
                 msg += " (" + L.nuslam_last_hip_error().decode() + ")"
         except Exception:
             pass
@@ -154,6 +162,39 @@ def _chk(rc, where):
 
 def _p(a):
     return a.ctypes.data_as(_dp)
+
+
+def build_info():
+    """'csrc=<hash>' of the kernel sources the loaded library was built from."""
+    return lib().nuslam_build_info().decode()
+
+
+class Comm:
+    """nuslam_comm_t: the RCCL communicator of the batch reduction (one rank per GPU)."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _chk(lib().nuslam_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, uid, world, rank, device=0):
+        buf = (C.c_ubyte * COMM_ID_BYTES)(*uid)
+        h = C.c_void_p()
+        _chk(lib().nuslam_comm_create(buf, world, rank, device, C.byref(h)), "comm_create")
+        self._h = h
+        self.world, self.rank = world, rank
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().nuslam_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count():
@@ -331,6 +372,14 @@ class Batch:
         _chk(lib().nuslam_batch_stats(self._h, _p(out), out.size), "batch_stats")
         return out
 
+    def reduce_stats(self, comm):
+        """All ranks: (total, per_rank) of the statistics vector, gathered over RCCL and added in rank order on the device."""
+        n = 2 * self.len + 6
+        total = np.zeros(n)
+        per_rank = np.zeros((comm.world, n))
+        _chk(lib().nuslam_batch_reduce_stats(self._h, comm._h, _p(total), n, _p(per_rank)), "batch_reduce_stats")
+        return total, per_rank
+
     def set_deferred(self, enable=True):
         _chk(lib().nuslam_batch_set_deferred(self._h, 1 if enable else 0), "batch_set_deferred")
 
@@ -462,6 +511,15 @@ class EKF:
         st = np.ascontiguousarray(state, dtype=np.float64)
         cv = np.asfortranarray(cov, dtype=np.float64)
         _chk(lib().nuslam_ekf_restore(self._h, _p(st), cv.ctypes.data_as(_dp), self.len, int(seen)), "ekf_restore")
+
+    def snapshot(self):
+        """(state, cov, seen) in one call -- what restore() takes back."""
+        st = np.zeros(self.len)
+        cv = np.zeros((self.len, self.len), order="F")
+        seen = C.c_int()
+        _chk(lib().nuslam_ekf_snapshot(self._h, _p(st), self.len, cv.ctypes.data_as(_dp), self.len, C.byref(seen)),
+             "ekf_snapshot")
+        return st, cv, seen.value
 
     def sync(self):
         _chk(lib().nuslam_ekf_sync(self._h), "ekf_sync")

@@ -55,7 +55,21 @@ def test_no_cpu_fallback():
 
 def test_error_strings():
     L = nh.lib()
-    for code in range(7):
+    for code in range(9):
         assert L.nuslam_strerror(code)
     assert b"logic_error" in L.nuslam_strerror(nh.E_BOUNDS)
     assert b"runtime_error" in L.nuslam_strerror(nh.E_SINGULAR)
+
+
+def test_build_info_names_the_kernel_sources():
+    info = nh.build_info()
+    assert re.fullmatch(r"csrc=[0-9a-f]{16}", info), info
+
+
+def test_rccl_reduction_refuses_without_a_device():
+    """The batch reduction binds RCCL at run time; on a host without a GPU it must fail loudly, not pretend."""
+    if nh.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(nh.NuslamError) as ei:
+        nh.Comm(bytes(nh.COMM_ID_BYTES), 1, 0, 0)
+    assert ei.value.code in (nh.E_NODEV, nh.E_COMM)
