@@ -70,6 +70,8 @@ def parse():
                     help="batch workload: per-filter Monte-Carlo traces generated on the device by the simulator kernels "
                          "(default), or one host-made trace per rank replayed by every filter")
     ap.add_argument("--no-pairing", action="store_true", help="one k_update launch per correction (disable k_update2)")
+    ap.add_argument("--per-correction", action="store_true",
+                    help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
     ap.add_argument("--min-timed-ms", type=float, default=1e3 * TARGET_TIMED_S)
     ap.add_argument("--blocks", type=int, default=0, help="run exactly this many timed K-step blocks (0: until --min-timed-ms)")
@@ -311,6 +313,8 @@ def main():
         bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
     if args.deferred:
         bt.set_deferred(True)
+    if args.per_correction or args.no_pairing or args.group:
+        bt.set_tick_mode(0)
     if args.no_pairing:
         bt.set_pairing(False)
     elif args.group:
@@ -353,6 +357,9 @@ def main():
     gemm_ms, gemm_n = bt.profile_read(nh.K_DENSE_GEMM)
     dupd_ms, dupd_n = bt.profile_read(nh.K_UPDATE_DEFERRED)
     flush_ms, flush_n = bt.profile_read(nh.K_FLUSH)
+    chain_ms, chain_n = bt.profile_read(nh.K_TICK_CHAIN)
+    panel_ms, panel_n = bt.profile_read(nh.K_TICK_PANELS)
+    apply_ms, apply_n = bt.profile_read(nh.K_TICK_APPLY)
     bt.profile(False)
     bad, st = bt.status()
     if st != 0:
@@ -443,7 +450,10 @@ def main():
                               "mean_nees": float(total[2 * L + 3] / max(n_filters_seen, 1)),
                               "mean_trace_P": float(total[2 * L + 4] / max(n_filters_seen, 1))}
     sweep_kernel, units = "k_update", 1
-    if pair_n > sweep_n:
+    if apply_n:
+        # the tick pipeline: ONE pass over P applies all m corrections of the tick
+        sweep_ms, sweep_n, sweep_kernel, units = apply_ms, apply_n, "k_tick_apply", m
+    elif pair_n > sweep_n:
         # most corrections went through k_update2: TWO corrections per pass over P (bit-identical to two k_update)
         sweep_ms, sweep_n, sweep_kernel, units = pair_ms, pair_n, "k_update2", 2
     if sweep_n:
@@ -471,6 +481,9 @@ def main():
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
+        if apply_n:
+            out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / max(chain_n, 1), "tick_panels": 1e3 * panel_ms / max(panel_n, 1),
+                                     "tick_apply": 1e3 * apply_ms / apply_n})
     if args.deferred and flush_n:
         # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved)
         per_launch_bytes = 2.0 * L * L * w * B

@@ -172,6 +172,13 @@ int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
  * four-per-pass kernel (k_updatej, also bit-identical, currently slower than pairs). */
 int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
+/* How a known-id tick (nuslam_ekf_tick with known_ids, nuslam_batch_run on a trace with ids) applies its corrections.
+ * mode 1 (default): the tick pipeline -- the serial part of all corrections first (a 35 x 35 block and 35 state
+ * entries carried through the corrections: H, S^-1, K, the innovation), then the O(len) gain / prior-row strips,
+ * then ONE pass over the covariance that carries every tile through all corrections: 2 len^2 w bytes per tick.
+ * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
+ * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle. */
+int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */
 /* The simulator's loop, nuturtlesim/src/tube_world.cpp:509-533, run on the device for every filter of a batch and
@@ -231,7 +238,10 @@ typedef enum {
     NUSLAM_K_UPDATE_DEFERRED = 4, /* one correction in factor form, O(len) (deferred mode) */
     NUSLAM_K_FLUSH = 5,        /* the rank-2J pass that applies a tick's pending corrections (deferred mode) */
     NUSLAM_K_UPDATE2 = 6,      /* two consecutive corrections in one pass over P (bit-identical to two NUSLAM_K_UPDATE) */
-    NUSLAM_K_COUNT = 7
+    NUSLAM_K_TICK_CHAIN = 7,   /* tick pipeline: the serial part of a round of corrections (one workgroup per filter) */
+    NUSLAM_K_TICK_PANELS = 8,  /* tick pipeline: the O(len) gain / prior-row strips of the round */
+    NUSLAM_K_TICK_APPLY = 9,   /* tick pipeline: the one pass over P that applies the whole round -- the HBM-bound kernel */
+    NUSLAM_K_COUNT = 10
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

@@ -32,7 +32,7 @@ template <typename T>
 __device__ inline Pack16<T> load_stream(const T* p)
 {
     typedef T vt __attribute__((ext_vector_type(16 / sizeof(T))));
-#ifdef NUSLAM_NO_STREAM
+#if defined(NUSLAM_NO_STREAM) || defined(NUSLAM_LOAD_PLAIN)
     const vt y = *reinterpret_cast<const vt*>(p);
 #else
     const vt y = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
@@ -49,7 +49,11 @@ __device__ inline void store_stream(T* p, const Pack16<T>& x)
     vt y;
 #pragma unroll
     for (int e = 0; e < (int)(16 / sizeof(T)); ++e) y[e] = x.v[e];
-#ifdef NUSLAM_NO_STREAM
+#if defined(NUSLAM_STORE_SC1)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(y) : "memory");   // write-through, line dropped from L2
+#elif defined(NUSLAM_STORE_SC01)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(y) : "memory");
+#elif defined(NUSLAM_NO_STREAM) || defined(NUSLAM_STORE_PLAIN)
     *reinterpret_cast<vt*>(p) = y;
 #else
     __builtin_nontemporal_store(y, reinterpret_cast<vt*>(p));
@@ -337,5 +341,6 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 
 #include "ekf_update.h"
 #include "ekf_update2.h"
+#include "ekf_tick.h"
 #include "ekf_updatej.h"
 #include "ekf_deferred.h"

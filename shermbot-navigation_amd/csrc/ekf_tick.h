@@ -1,0 +1,609 @@
+// ekf_tick.h -- one tick's corrections as THREE kernels and ONE pass over the covariance.
+//
+// The m corrections of a tick (slam.cpp:279-318: update() per marker, each relinearised at the state the previous one
+// left) are sequential, but what makes them sequential is small.  Correction s touches every element of P through
+//
+//     P_s(i,j) = sum_k M_s(i,k) P_{s-1}(k,j),   k ascending over {0,1,2} U {i} U {c_s, c_s+1},   M_s = I - K_s H_s
+//
+// (slam_library.cpp:279 with the exactly-zero terms dropped -- the sweep formula of ekf_update.h), and the only inputs
+// of that formula that are not the element itself are, per ROW i, the gain K_s(i,:) (two numbers) and, per COLUMN j,
+// the five prior entries R_s(q,j) = P_{s-1}(set_s[q], j).  Those are O(len) numbers per correction, and they obey the
+// same recurrence restricted to a PANEL: with U = {0,1,2} U {c_t, c_t+1 : t = 1..m} (3 + 2m indices),
+//
+//     rows    RP[p][j] = P(U[p], j)      columns CP[i][p] = P(i, U[p])      block BK[p][p'] = P(U[p], U[p'])
+//
+// every entry of RP / CP / BK after correction s is the sweep formula applied to entries of RP / CP / BK after
+// correction s-1.  So:
+//
+//   k_tick_chain   one workgroup per filter: the serial part.  Carries BK (35 x 35) and the 35 state entries at U
+//                  through the m corrections: decision chain (slam.cpp:295-316), initializeLandmark (:255-261), z_hat
+//                  (:150-160), H (:162-186), S, S^-1 (:270), K and M at the rows of U, the state at U -- and writes a
+//                  PLAN per correction: H, S^-1, the innovation, M(U[p],:), P_{s-1}(set_s, U[p]).   Latency-bound
+//                  (transcendentals); nothing in it is O(len).
+//   k_tick_panels  one thread per state index, no serial dependency left: replays the plan on its column of RP and
+//                  its row of CP and emits, per correction, R_s(:, j) (5 x len) and K_s(i,:) (len x 2), and the new
+//                  state vector.  The plan's coefficients are wave-uniform: they arrive as scalar loads and feed the
+//                  FMAs as SGPR operands.
+//   k_tick_apply   THE pass over P: every tile is read once, carried through all m corrections in registers with the
+//                  K / R strips streamed from L2, and written once -- 2 len^2 w bytes per TICK instead of per
+//                  correction (or per pair).
+//
+// Every floating-point operation on every element is the one k_update performs, in the same order, with the same
+// rounding to the storage type after each correction; only where it is executed has changed.  The result is therefore
+// bit-identical to m launches of k_update (tests/test_gpu_tick.py) and hence to the oracle's update().
+#pragma once
+
+namespace nuslam {
+
+constexpr int kTickJ = 16;                 // corrections per round (a tick with more markers runs several rounds)
+constexpr int kTickNU = 3 + 2 * kTickJ;    // panel indices
+
+// the markers of one round, for every filter
+struct TickObs {
+    const double* a;       // marker x (cartesian != 0) or range, [b * stride + off + s]; null -> a0[s]
+    const double* b;       // marker y or bearing
+    const int* ids;        // known 1-based ids, same indexing; null -> id0[s]
+    long long stride, off;
+    double a0[kTickJ], b0[kTickJ];
+    int id0[kTickJ];
+    int cartesian;
+    int log_slot0;         // id_log index of marker 0 of this round, or -1
+    int J;                 // markers in this round, 1..kTickJ
+};
+
+// what one correction leaves for k_tick_panels and k_tick_apply (per filter, per marker)
+struct alignas(16) TickStep {
+    int skip;              // the marker changes nothing in P (gray zone, break, bad id, singular S)
+    int init;              // initializeLandmark ran: state rows c, c+1 become lxy before the correction (or instead of it)
+    int c;                 // first state index of the landmark
+    int id;                // resolved id
+    double Hc[10], Sinv[4], dz[2], lxy[2];
+    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]
+    double BR[5][kTickNU + 1];     // P_{s-1}(set_s[q], U[p])
+};
+
+// Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
+// (__syncthreads() also drains vmcnt, i.e. waits ~1 us for the acknowledgement of every plan store in flight).
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ the serial chain
+template <typename T>
+__global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+                                                    TickStep* __restrict__ plan)
+{
+    constexpr int NU = kTickNU;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = v.ld;
+    const double* s = v.s_in + (size_t)b * ld;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    TickStep* pl = plan + (size_t)b * kTickJ;
+    const int J = o.J;
+
+    __shared__ double BK[2][NU][NU + 1];          // P(U[p], U[p']) before / after the current correction
+    __shared__ double SM[2][NU + 1];              // state at U
+    __shared__ double MPl[NU][8];
+    __shared__ double zr[kTickJ], zphi[kTickJ];   // the markers in polar form (slam.cpp:286)
+    __shared__ double hd[20];                     // Hc[10], Sinv[4], lx, ly, dz0, dz1, z_hat range, un-rotated bearing
+    __shared__ int hi[2];
+    __shared__ int Ush[NU + 1];
+    __shared__ int idsh[kTickJ];
+
+    if (tid < kTickJ) {
+        int id = 0;
+        if (tid < J) id = o.ids ? o.ids[b * o.stride + o.off + tid] : o.id0[tid];
+        idsh[tid] = id;
+        const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;      // always a readable index
+        Ush[3 + 2 * tid] = c;
+        Ush[4 + 2 * tid] = c + 1;
+    }
+    if (tid < 3) Ush[tid] = tid;
+    __syncthreads();
+    for (int e = tid; e < NU * NU; e += 256) {
+        const int p = e / NU, q = e % NU;
+        BK[0][p][q] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+    }
+    if (tid < NU) SM[0][tid] = s[Ush[tid]];
+    if (wave == 3 && lane < kTickJ) {             // all markers' polar forms at once, one lane each
+        double a = 0.0, bb = 0.0;
+        if (lane < J) {
+            a = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
+            bb = o.b ? o.b[b * o.stride + o.off + lane] : o.b0[lane];
+        }
+        double r, phi;
+        if (o.cartesian) cartesian2polar(a, bb, r, phi);
+        else { r = a; phi = bb; }
+        zr[lane] = r;
+        zphi[lane] = phi;
+    }
+    const int* ci = v.c_in + b * C_WORDS;
+    int seen = ci[C_SEEN], brk = ci[C_BRK], status = ci[C_STATUS];
+    const int cached = ci[C_SEEN_CACHED];
+    __syncthreads();
+
+    int cur = 0;
+    bool theta_raw = false;               // SM[cur][0] holds theta + K nu of the previous correction, not yet wrapped
+    for (int st = 0; st < J; ++st) {
+        const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
+        seen = d.new_seen; brk = d.new_brk; status = d.new_status;
+        TickStep* ps = pl + st;
+        if (tid == 0 && v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = d.id;
+        if (d.skip) {
+            if (tid == 0) { ps->skip = 1; ps->init = 0; ps->c = 3; ps->id = d.id; }
+            continue;
+        }
+        const int pos = 3 + 2 * st, c = d.c;
+        const int sp[5] = { 0, 1, 2, pos, pos + 1 };                    // positions of set_s in U
+        const int setv[5] = { 0, 1, 2, c, c + 1 };
+        double (*B0)[NU + 1] = BK[cur];
+        double (*B1)[NU + 1] = BK[cur ^ 1];
+        const double* S0 = SM[cur];
+
+        // ---- three chains side by side.  The heading left by the previous correction is still the raw sum
+        // theta + K nu; its re-normalisation (:276: sin, cos, atan2) runs on wave 0 WHILE wave 1 turns the landmark
+        // offset into polar form (the first half of computeTheoreticalMeasurement, :150-158: sqrt, atan2, sin, cos,
+        // atan2 -- none of which reads the heading) and wave 2 forms H, S, S^-1 (which do not read it either).  Only a
+        // first sighting needs the heading first (initializeLandmark, :255-261).
+        if (d.init) {
+            if (wave == 0 && theta_raw) {
+                const double th = normalize_angle(SM[cur][0]);
+                if (lane == 0) SM[cur][0] = th;
+            }
+            lds_barrier();
+        }
+        if (wave == 0 && theta_raw && !d.init) {
+            const double th = normalize_angle(SM[cur][0]);
+            if (lane == 0) SM[cur][0] = th;
+        } else if (wave == 1 || wave == 2) {
+            const double x = S0[1], y = S0[2];
+            double lx, ly;
+            if (d.init) {                                               // initializeLandmark, slam_library.cpp:255-261
+                const double th = S0[0], r = zr[st], phi = zphi[st];
+                lx = x + r * cos(phi + th);
+                ly = y + r * sin(phi + th);
+            } else { lx = S0[pos]; ly = S0[pos + 1]; }
+            if (wave == 2) {
+                double Hc[10], S[4], Si[4], pb[5][5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+#pragma unroll
+                    for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = B0[sp[q2]][sp[q]];       // pb[q][q2] = P(set[q2], set[q])
+                jacobian_compact(x, y, lx, ly, Hc);                     // :268
+                innovation_cov_block(pb, Hc, v.R, S);                   // H P H^T + R, :270
+                const int sing = inv2(S, Si);
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) hd[q] = Hc[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hd[10 + q] = Si[q];
+                    hd[14] = lx; hd[15] = ly;
+                    hi[0] = sing;
+                }
+            } else {
+                const double mx = lx - x, my = ly - y;                  // measurement(): :152-156
+                double zr_h, zb_h;
+                cartesian2polar(mx, my, zr_h, zb_h);
+                if (lane == 0) { hd[18] = zr_h; hd[19] = zb_h; }
+            }
+        }
+        theta_raw = false;
+        lds_barrier();
+        if (wave == 1) {
+            const double zb = normalize_angle(hd[19] - S0[0]);          // :157-159, the heading now re-normalised
+            if (lane == 0) { hd[16] = zr[st] - hd[18]; hd[17] = zphi[st] - zb; }        // :272, bearing not wrapped
+        }
+        lds_barrier();
+        const double lx = hd[14], ly = hd[15];
+        if (hi[0]) {                                                    // singular S: update() throws after the init
+            if (status == 0) status = kStatusSingular;
+            if (tid == 0) {
+                ps->skip = 1; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
+            }
+            if (d.init && tid < NU) {
+                const int i = Ush[tid];
+                if (i == c) SM[cur][tid] = lx;
+                if (i == c + 1) SM[cur][tid] = ly;
+            }
+            lds_barrier();
+            continue;
+        }
+        const double dz0 = hd[16], dz1 = hd[17];
+
+        // ---- K and M at the rows of U (one row per thread), the state at U, and the plan of this correction
+        if (tid < NU) {
+            const int p = tid, i = Ush[p];
+            double pc[5], Hc[10], Si[4], KP[2], m[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];          // P(U[p], set[q])
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = hd[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si[q] = hd[10 + q];
+            gain_row(pc, Hc, Si, i, setv, KP, m);
+            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { MPl[p][q] = m[q]; ps->MP[p][q] = m[q]; }
+            MPl[p][5] = bef; MPl[p][6] = aft;
+            ps->MP[p][5] = bef; ps->MP[p][6] = aft; ps->MP[p][7] = 0.0;
+            double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : S0[p];
+            double acc = 0.0;
+            acc = fma(KP[0], dz0, acc);
+            acc = fma(KP[1], dz1, acc);
+            sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
+            SM[cur ^ 1][p] = sv;
+        } else if (tid >= 64 && tid < 64 + 5 * 8) {                     // the five prior rows at the columns of U
+            const int q = (tid - 64) >> 3;
+            for (int p = (tid - 64) & 7; p < NU; p += 8) ps->BR[q][p] = B0[sp[q]][p];
+        } else if (tid == 128) {
+            ps->skip = 0; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
+            ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
+        }
+        lds_barrier();
+
+        // ---- the block after this correction
+        for (int e = tid; e < NU * NU; e += 256) {
+            const int p = e / NU, pp = e % NU;
+            double mrow[5], r[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { mrow[q] = MPl[p][q]; r[q] = B0[sp[q]][pp]; }
+            B1[p][pp] = p1_entry<T>(mrow, r, B0[p][pp], MPl[p][5], MPl[p][6]);
+        }
+        lds_barrier();
+        cur ^= 1;
+        theta_raw = true;
+    }
+    if (tid == 0) {
+        int* co = v.c_out + b * C_WORDS;
+        co[C_SEEN] = seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = brk; co[C_STATUS] = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the panels
+// 128 threads = 64 state indices x 2 roles: wave 0 owns COLUMN t of the row panel (RP[p] = P(U[p], t)), wave 1 owns ROW t
+// of the column panel (CP[p] = P(t, U[p])) and state entry t.  The whole plan of the round (61 KB) is staged in LDS
+// once; its coefficients are wave-uniform and come back as broadcast ds_reads (scalar loads were tried first: ~60
+// dependent s_load + s_waitcnt per correction made the kernel latency-bound at 4 us per correction).
+// Only the panel entries a later correction still reads are carried: rows / columns 0, 1, 2 and those of the
+// landmarks of LATER markers (a landmark's own rows are consumed at its marker) -- half the work of the full panel.
+constexpr int kPlanWords = (int)(sizeof(TickStep) / 8);
+
+template <typename T>
+__global__ __launch_bounds__(128) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
+                                                     const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
+                                                     double* __restrict__ Rbuf)
+{
+    constexpr int NU = kTickNU;
+    const int b = blockIdx.y;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ld = v.ld, L = v.L;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    const int J = o.J;
+    double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
+    double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
+
+    extern __shared__ double plan_l[];                                  // [J][kPlanWords]
+    {
+        const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
+        Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
+        const int n16 = J * (int)(sizeof(TickStep) / 16);
+        for (int e = threadIdx.x; e < n16; e += 128) dst[e] = src[e];
+    }
+
+    int U[NU];
+    U[0] = 0; U[1] = 1; U[2] = 2;
+#pragma unroll
+    for (int st = 0; st < kTickJ; ++st) {
+        int id = 0;
+        if (st < J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+        const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
+        U[3 + 2 * st] = c;
+        U[4 + 2 * st] = c + 1;
+    }
+
+    if (role == 0) {
+        // ---- column t of the five-row strips R_s and of the row panel
+        const bool live = t < L;
+        const T* col = Pb + (size_t)(live ? t : 0) * ld;
+        double RP[NU];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) RP[p] = (double)col[U[p]];
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < kTickJ; ++st) {             // (no break / continue: the loop must unroll, RP is indexed by st)
+            const TickStep* ps = reinterpret_cast<const TickStep*>(plan_l) + (st < J ? st : 0);
+            if (st < J && !ps->skip) {
+                const int pos = 3 + 2 * st;
+                const double rs[5] = { RP[0], RP[1], RP[2], RP[pos], RP[pos + 1] };   // P_{s-1}(set_s[q], t)
+                if (live) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
+                }
+                // rows 0..2 and the rows of later markers, six at a time: their M rows (wave-uniform, 7 numbers each)
+                // are read together, then the six chains advance stage by stage
+#pragma unroll
+                for (int g = 0; g < (NU + 5) / 6; ++g) {
+                    double mm[6][7], acc[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int pp = 6 * g + k;
+                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                        if (on) {
+#pragma unroll
+                            for (int q = 0; q < 7; ++q) mm[k][q] = ps->MP[pp][q];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int pp = 6 * g + k;
+                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                        if (on) acc[k] = mm[k][0] * rs[0];
+                    }
+#pragma unroll
+                    for (int stg = 1; stg < 7; ++stg)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int pp = 6 * g + k;
+                            const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                            if (on) {
+                                if (stg < 3) acc[k] = fma(mm[k][stg], rs[stg], acc[k]);
+                                else if (stg == 3) acc[k] = fma(mm[k][5], RP[pp], acc[k]);
+                                else if (stg < 6) acc[k] = fma(mm[k][stg - 1], rs[stg - 1], acc[k]);
+                                else RP[pp] = (double)(T)fma(mm[k][6], RP[pp], acc[k]);
+                            }
+                        }
+                }
+            }
+        }
+    } else {
+        // ---- row t of the gains K_s and of the column panel; state entry t
+        const bool live = t < ld;
+        const int tr = live ? t : 0;
+        double CP[NU];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) CP[p] = (double)Pb[(size_t)U[p] * ld + tr];
+        double sv = v.s_in[(size_t)b * ld + tr];
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < kTickJ; ++st) {
+            const TickStep* ps = reinterpret_cast<const TickStep*>(plan_l) + (st < J ? st : 0);
+            const int c = ps->c;
+            const bool init = ps->init != 0;
+            if (st < J && ps->skip && init) {                           // the landmark was initialised before update() threw
+                if (t == c) sv = ps->lxy[0];
+                if (t == c + 1) sv = ps->lxy[1];
+            }
+            if (st < J && !ps->skip) {
+                const int pos = 3 + 2 * st;
+                const int setv[5] = { 0, 1, 2, c, c + 1 };
+                const double pc[5] = { CP[0], CP[1], CP[2], CP[pos], CP[pos + 1] };   // P_{s-1}(t, set_s[q])
+                double Hc[10], Si[4], K[2], m[5];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
+                gain_row(pc, Hc, Si, t, setv, K, m);
+                if (live) {
+                    Kb[(size_t)(st * 2 + 0) * ld + t] = K[0];
+                    Kb[(size_t)(st * 2 + 1) * ld + t] = K[1];
+                }
+                const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
+                double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;
+                double acc = 0.0;
+                acc = fma(K[0], ps->dz[0], acc);
+                acc = fma(K[1], ps->dz[1], acc);
+                s0 = s0 + acc;                                          // :275
+                if (t == 0) s0 = normalize_angle(s0);                   // :276
+                sv = s0;
+#pragma unroll
+                for (int g = 0; g < (NU + 5) / 6; ++g) {  // (as above, for the columns 0..2 and those of later markers)
+                    double rr[6][5], acc[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int pp = 6 * g + k;
+                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                        if (on) {
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) rr[k][q] = ps->BR[q][pp];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int pp = 6 * g + k;
+                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                        if (on) acc[k] = m[0] * rr[k][0];
+                    }
+#pragma unroll
+                    for (int stg = 1; stg < 7; ++stg)
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int pp = 6 * g + k;
+                            const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
+                            if (on) {
+                                if (stg < 3) acc[k] = fma(m[stg], rr[k][stg], acc[k]);
+                                else if (stg == 3) acc[k] = fma(bef, CP[pp], acc[k]);
+                                else if (stg < 6) acc[k] = fma(m[stg - 1], rr[k][stg - 1], acc[k]);
+                                else CP[pp] = (double)(T)fma(aft, CP[pp], acc[k]);
+                            }
+                        }
+                }
+            }
+        }
+        if (live) v.s_out[(size_t)b * ld + t] = sv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the pass over P
+// Tiling as k_update: a wave owns 64*VEC consecutive rows x 16 columns, a lane moves 16 bytes per column; WAVES column
+// strips per workgroup.  Everything the J corrections need besides the tile is staged in LDS ONCE, in one burst of loads
+// issued ahead of the tile's: K_s at the workgroup's rows (J x 2 x 64*VEC doubles, shared by its waves) and R_s at each
+// wave's 16 columns (J x 5 x 16 doubles per wave).  The loop over the corrections then touches only LDS and registers:
+// per correction and lane two 16-byte reads of K, ten FMAs per row for M(i, set), and per column five broadcast reads of
+// R and seven FMAs per element -- the FMA chain of k_update, operation for operation.
+template <typename T, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const TickStep* __restrict__ plan,
+                                                           const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
+                                                           const T* __restrict__ Pin, T* __restrict__ Pout)
+{
+    constexpr int CW = 16;
+    typedef Pack16<T> vec_t;
+    typedef Pack16<double> d2_t;
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int ROWS = 64 * VEC;                        // rows of a workgroup
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = v.ld, L = v.L;
+    const int rbase = blockIdx.x * ROWS;
+    const int row0 = rbase + lane * VEC;
+    const int strip = blockIdx.y * WAVES + wave;
+    const bool active = strip * CW < L;
+    const int j0 = active ? strip * CW : 0;
+    const bool rows_ok = row0 < ld;
+    const int rowc = rows_ok ? row0 : 0;
+    const int ncol = (L - j0) < CW ? (L - j0) : CW;
+    const TickStep* pl = plan + (size_t)b * kTickJ;
+
+    extern __shared__ double lds_apply[];
+    double* Ks = lds_apply;                               // [J][2][ROWS]
+    double* Rs = lds_apply + (size_t)J * 2 * ROWS + (size_t)wave * J * 5 * CW;   // this wave's [J][5][CW]
+
+    // ---- one burst of loads: K (workgroup-cooperative), R (per wave), then the tile
+    constexpr int KCH = kTickJ * 2 * ROWS / 2 / (64 * WAVES);     // 16-byte chunks of K per thread, at most
+    d2_t kst[KCH];
+    const double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
+    const int nk = J * 2 * (ROWS / 2);                    // chunks: [J*2 rows][ROWS/2]
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int k = threadIdx.x + i * 64 * WAVES;
+        const int kk = k < nk ? k : 0;
+        const int row = kk / (ROWS / 2), piece = kk % (ROWS / 2);
+        int gr = rbase + 2 * piece;
+        gr = gr < ld ? gr : 0;                            // rows past the padded length: any readable address (never used)
+        kst[i] = *reinterpret_cast<const d2_t*>(Kb + (size_t)row * ld + gr);
+    }
+    constexpr int RCH = kTickJ * 5 * CW / 2 / 64;         // = 10 chunks of R per lane, at most
+    d2_t rst[RCH];
+    const double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld + j0;
+    const int nr = J * 5 * (CW / 2);
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+        const int k = lane + i * 64;
+        const int kk = k < nr ? k : 0;
+        const int row = kk / (CW / 2), piece = kk % (CW / 2);
+        // (columns past len in the last strip: still inside the row's ld entries; they feed only columns never stored)
+        rst[i] = *reinterpret_cast<const d2_t*>(Rb + (size_t)row * ld + 2 * piece);
+    }
+    const T* Pr = Pin + (size_t)b * v.p_stride + (size_t)j0 * ld + rowc;
+    vec_t p[CW];
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int k = threadIdx.x + i * 64 * WAVES;
+        if (k < nk) *reinterpret_cast<d2_t*>(Ks + 2 * (size_t)k) = kst[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+        const int k = lane + i * 64;
+        if (k < nr) *reinterpret_cast<d2_t*>(Rs + 2 * (size_t)k) = rst[i];
+    }
+    __syncthreads();
+    if (!active) return;
+
+    // the step's scalars (skip, c, H) are fetched one correction ahead: a scalar load issued at the top of the
+    // iteration that needs it would expose its latency sixteen times
+    int nskip = pl[0].skip, nc = pl[0].c;
+    double nH[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) nH[q] = pl[0].Hc[q];
+    for (int st = 0; st < J; ++st) {
+        const int skip = nskip, c = nc;
+        double Hc[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) Hc[q] = nH[q];
+        {
+            const TickStep* pn = pl + (st + 1 < J ? st + 1 : st);
+            nskip = pn->skip; nc = pn->c;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) nH[q] = pn->Hc[q];
+        }
+        if (skip) continue;                               // wave-uniform
+        double m[VEC][5], bef[VEC], aft[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e += 2) {
+            const d2_t k0 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 0) * ROWS + lane * VEC + e);
+            const d2_t k1 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 1) * ROWS + lane * VEC + e);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int i = row0 + e + h2;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    double kh = 0.0;                      // exactly gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+                    kh = fma(k0.v[h2], Hc[0 + 2 * q], kh);
+                    kh = fma(k1.v[h2], Hc[1 + 2 * q], kh);
+                    const int sidx = q < 3 ? q : c + (q - 3);
+                    m[e + h2][q] = (i == sidx ? 1.0 : 0.0) - kh;
+                }
+                bef[e + h2] = ((i > 2) && (i < c)) ? 1.0 : 0.0;
+                aft[e + h2] = (i > c + 1) ? 1.0 : 0.0;
+            }
+        }
+        const double* Rst = Rs + (size_t)st * 5 * CW;
+        // the prior rows of eight columns at a time, as 20 broadcast ds_read_b128 issued together (one dependent
+        // read-then-FMA group per column left the loop waiting on LDS latency sixteen times per correction)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            d2_t rr[5][4];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rr[q][k] = *reinterpret_cast<const d2_t*>(Rst + q * CW + half * 8 + 2 * k);
+            // sweep_entry's chain, written stage by stage over the 8 x VEC independent elements: seven dependent FMAs
+            // per element, sixteen (or thirty-two) chains in flight
+            double acc[8][VEC], pij[8][VEC];
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    pij[j8][e] = (double)p[half * 8 + j8].v[e];
+                    acc[j8][e] = m[e][0] * rr[0][j8 >> 1].v[j8 & 1];
+                }
+#pragma unroll
+            for (int q = 1; q < 3; ++q)
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(bef[e], pij[j8][e], acc[j8][e]);
+#pragma unroll
+            for (int q = 3; q < 5; ++q)
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) p[half * 8 + j8].v[e] = (T)fma(aft[e], pij[j8][e], acc[j8][e]);
+        }
+    }
+    if (!rows_ok) return;
+    T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
+#pragma unroll
+    for (int jj = 0; jj < CW; ++jj)
+        if (jj < ncol) store_stream(Pw + (size_t)jj * ld, p[jj]);
+}
+
+} // namespace nuslam

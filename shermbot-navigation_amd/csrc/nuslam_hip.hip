@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -83,6 +84,10 @@ struct nuslam_batch {
     void* wF = nullptr;
     bool f_staged = false;
     // deferred application: pending rank-2 factors U_i = K_i, V_i = H_i P_{i-1}
+    // tick pipeline (ekf_tick.h): plan + K / R strips of one round of up to kTickJ corrections
+    int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
+                               // -1: whichever is faster for this handle (see tick_pipeline_pays)
+    TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
     bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
     int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
     std::vector<int> host_seen;   // host mirror of every filter's `seen`; valid while only known-id calls were made
@@ -146,6 +151,22 @@ int launch(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 blo
         h->pending[kid].emplace_back(e0, e1);
     } else {
         hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+    }
+    HIPCHK(hipGetLastError());
+    return NUSLAM_OK;
+}
+
+// the same with dynamic LDS
+template <typename... KArgs, typename... Args>
+int launch_lds(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, Args... args)
+{
+    if (h->prof && kid >= 0) {
+        hipEvent_t e0 = get_event(h), e1 = get_event(h);
+        if (!e0 || !e1) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; }
+        hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, e0, e1, 0, args...);
+        h->pending[kid].emplace_back(e0, e1);
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, lds, h->stream, args...);
     }
     HIPCHK(hipGetLastError());
     return NUSLAM_OK;
@@ -257,6 +278,9 @@ int associate_finish(nuslam_batch* h)
 int sweep_waves(const nuslam_batch* h, int vec, int strips)
 {
     const long long wgs8 = (long long)((h->ld + 64 * vec - 1) / (64 * vec)) * ((strips + 7) / 8) * h->B;
+#ifdef NUSLAM_PHASE_CLOCK
+    if (const char* f = getenv("NUSLAM_FORCE_WAVES")) return atoi(f) == 4 ? 4 : 8;     // experiments only (debug builds)
+#endif
     return wgs8 <= h->n_cu ? 8 : 4;
 }
 
@@ -353,6 +377,77 @@ int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, 
     return NUSLAM_OK;
 }
 
+// The tick pipeline moves P once per tick instead of once per pair of corrections, at the price of a serial chain
+// (~3 us per correction, one workgroup per filter) and the strip kernel.  With many filters those run side by side and
+// the pass over P dominates: measured 1.8x at 1024 x N = 200.  For ONE filter the chain is exposed (N = 1000: 130 us
+// per tick against 121 us for eight pair launches) until chain and pass of consecutive ticks overlap.
+bool tick_pipeline_pays(const nuslam_batch* h, int m)
+{
+    if (h->tick_mode >= 0) return h->tick_mode == 1;
+    return h->B >= 2 && m >= 2;
+}
+
+// The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
+// k_tick_panels (the O(len) strips, one thread per state index), k_tick_apply (the one pass over P).
+int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
+                   const double* host_my)
+{
+    if (!h->tk_plan) {
+        const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+        HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
+        HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
+        HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * (size_t)h->B * kTickJ * 5 * h->ld));
+    }
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    const int waves = sweep_waves(h, vec, strips);
+    for (int i0 = 0; i0 < m; i0 += kTickJ) {
+        TickObs o;
+        o.J = (m - i0) < kTickJ ? (m - i0) : kTickJ;
+        o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
+        o.ids = host_ids ? nullptr : base.ids;
+        o.stride = base.stride; o.off = base.off + i0;
+        o.cartesian = base.cartesian;
+        o.log_slot0 = h->id_log ? i0 : -1;
+        for (int k = 0; k < kTickJ; ++k) {
+            const bool in = k < o.J;
+            o.a0[k] = (in && host_mx) ? host_mx[i0 + k] : (in ? base.a0 : 0.0);
+            o.b0[k] = (in && host_my) ? host_my[i0 + k] : (in ? base.b0 : 0.0);
+            o.id0[k] = (in && host_ids) ? host_ids[i0 + k] : (in ? base.id0 : 0);
+        }
+        View v = h->view();
+        int rc = NUSLAM_OK;
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T>, dim3(h->B), dim3(256), v, o, total, (const T*)h->P(),
+                                   h->tk_plan)));
+        if (rc) return rc;
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(128),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), (const TickStep*)h->tk_plan,
+                                       h->tk_K, h->tk_R)));
+        if (rc) return rc;
+        dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
+        const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
+        if (waves == 8)
+            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, o.J,
+                                           (const TickStep*)h->tk_plan, (const double*)h->tk_K, (const double*)h->tk_R,
+                                           (const T*)h->P(), (T*)h->Palt())));
+        else
+            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, o.J,
+                                           (const TickStep*)h->tk_plan, (const double*)h->tk_K, (const double*)h->tk_R,
+                                           (const T*)h->P(), (T*)h->Palt())));
+        if (rc) return rc;
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+        h->pidx ^= 1;
+    }
+    return NUSLAM_OK;
+}
+
 // One loop body of slam.cpp:250-319 for every filter of the batch.
 int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
             const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr,
@@ -363,6 +458,12 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark, in every
     // filter: then the caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does
     // not move.  host_ids: one id list for all filters; pf_ids: filter b's list at pf_ids + b * pf_stride.
+    if (known && tick_pipeline_pays(h, m) && !h->deferred && m > 0) {
+        rc = do_tick_rounds(h, base, m, total, host_ids, host_mx, host_my);
+        if (rc) return rc;
+        h->host_seen_valid = false;                 // (the mirror only serves the per-correction path's pairing)
+        return NUSLAM_OK;
+    }
     auto id_of = [&](int b, int i) { return host_ids ? host_ids[i] : pf_ids[(size_t)b * pf_stride + i]; };
     const bool have_ids = host_ids != nullptr || pf_ids != nullptr;
     bool plain = known && have_ids && h->host_seen_valid;
@@ -423,7 +524,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1024,6 +1125,13 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
     return NUSLAM_OK;
 }
 
+int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
+{
+    if (!h || mode < -1 || mode > 1) return NUSLAM_E_ARG;
+    h->tick_mode = mode;
+    return NUSLAM_OK;
+}
+
 int nuslam_batch_profile(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
@@ -1102,7 +1210,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (rc) return rc;
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
-    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group;
+    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode;
     rc = [&]() -> int {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipStreamSynchronize(s->stream));

@@ -1,0 +1,115 @@
+"""The tick pipeline (csrc/ekf_tick.h: k_tick_chain -> k_tick_panels -> k_tick_apply, ONE pass over P per tick) against
+the one-pass-per-correction kernel it replaces: the same floating-point operations on every element in the same order,
+so state, covariance, `seen`, resolved ids and latched status must agree BIT FOR BIT -- through landmark
+initialisation (INT_MAX diagonal), skipped markers (id < 0), the break of the marker loop (id > total_landmarks), bad
+ids, repeated ids inside one tick, fewer and more markers than one round of 16, fp32 storage and batches with
+per-filter ids.  (Against the oracle the default path is exercised by every other GPU test.)"""
+import numpy as np
+import pytest
+
+import _oracle as O
+from nuslam_hip import synth
+
+pytestmark = pytest.mark.gpu
+Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+
+
+def pair_of_filters(hip, n, dtype=0):
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+    a.as_batch().set_tick_mode(1)
+    bb = b.as_batch()
+    bb.set_tick_mode(0)
+    bb.set_pairing(False)                       # one k_update launch per correction: the reference arithmetic
+    return a, b
+
+
+def same(a, b):
+    return np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.seen == b.seen and a.status() == b.status()
+
+
+@pytest.mark.parametrize("n,m,dtype", [(10, 10, 0), (10, 3, 0), (40, 16, 0), (40, 16, 1), (60, 37, 0), (6, 1, 0)])
+def test_tick_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype):
+    tr = synth.make_trace(n, 6, m, straight_every=3)
+    a, b = pair_of_filters(hip, n, dtype)
+    for t in range(tr.ticks):
+        ia = a.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
+        ib = b.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
+        assert np.array_equal(ia, ib)
+        assert same(a, b), "tick %d" % t
+
+
+def test_tick_pipeline_decision_chain_edges(hip):
+    """skip (id -1), break (id > total_landmarks: the rest of the tick is dropped), out-of-range id (latched
+    NUSLAM_E_BOUNDS), the same landmark twice in one tick, a first sighting followed by a re-sighting in one tick."""
+    n, m = 12, 8
+    tr = synth.make_trace(n, 5, m)
+    a, b = pair_of_filters(hip, n)
+    cases = []
+    ids = tr.ids[0].copy(); ids[2] = -1; ids[5] = ids[1]; cases.append((ids, n))            # skip + duplicate (second one: re-sighting)
+    ids = tr.ids[1].copy(); ids[3] = -1; ids[4] = ids[0]; cases.append((ids, n))
+    ids = tr.ids[2].copy(); cases.append((ids, 5))                                          # total_landmarks = 5: ids > 5 break the loop
+    ids = tr.ids[3].copy(); ids[1] = ids[0]; ids[2] = ids[0]; cases.append((ids, n))        # three times the same landmark
+    for t, (ids, total) in enumerate(cases):
+        ia = a.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=ids, total_landmarks=total)
+        ib = b.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=ids, total_landmarks=total)
+        assert np.array_equal(ia, ib), (t, ia, ib)
+        assert same(a, b), "case %d" % t
+    ids = tr.ids[4].copy(); ids[2] = n + 3                                                  # bad id: both latch E_BOUNDS
+    for f in (a, b):
+        with pytest.raises(hip.NuslamError) as ei:
+            f.tick(tr.tw[4], tr.mx[4], tr.my[4], known_ids=ids)
+        assert ei.value.code == hip.E_BOUNDS
+    assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.seen == b.seen
+
+
+def test_tick_pipeline_batch_with_per_filter_ids(hip):
+    n, m, T, B = 30, 16, 4, 5
+    traces = [synth.make_trace(n, T, m, seed=300 + k) for k in range(B)]
+    tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces])
+    my = np.stack([t.my for t in traces]); ids = np.stack([t.ids for t in traces])
+    out = []
+    for mode in (1, 0):
+        bt = hip.Batch(B, n, Q, R)
+        bt.set_tick_mode(mode)
+        if mode == 0:
+            bt.set_pairing(False)
+        bt.load_trace(tw, mx, my, ids)
+        bt.run(0, T)
+        assert bt.status() == (-1, 0)
+        out.append([(bt.state(k), bt.cov(k), bt.seen(k)) for k in range(B)])
+    for k in range(B):
+        assert np.array_equal(out[0][k][0], out[1][k][0]) and np.array_equal(out[0][k][1], out[1][k][1])
+        assert out[0][k][2] == out[1][k][2]
+
+
+def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
+    """BASELINE configs[1] size: 2 ticks x 16 corrections from the oracle's post-initialisation snapshot: the tick
+    pipeline == the pair kernel == the single kernel bitwise, and within 1e-6 per entry of the oracle."""
+    n, m, T = 1000, 16, 2
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, T, m, landmarks=lm)
+    bx, by, wid = synth.warmup_observations(lm)
+    O.set_threads(O.usable_cpus())
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
+    o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=wid)
+    fs = []
+    for mode, pairing in ((1, True), (0, True), (0, False)):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+        g.restore(o.state.copy(), o.cov.copy(), o.seen)
+        bt = g.as_batch()
+        bt.set_tick_mode(mode)
+        bt.set_pairing(pairing)
+        fs.append(g)
+    for t in range(T):
+        o.tick(tw=tr.tw[t], mx=tr.mx[t], my=tr.my[t], known_ids=tr.ids[t])
+        for g in fs:
+            g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+    O.set_threads(1)
+    P0 = fs[0].cov
+    for g in fs[1:]:
+        assert np.array_equal(fs[0].state, g.state) and np.array_equal(P0, g.cov)
+    rel = lambda x, ref: float((np.abs(x - ref) / np.maximum(np.abs(ref), 1e-12 * np.abs(ref).max())).max())
+    es, ep = rel(fs[0].state, o.state), rel(P0, o.cov)
+    print("N=1000 tick pipeline: == pair kernel == single kernel bitwise; vs oracle state %.2e cov %.2e" % (es, ep))
+    assert es < 1e-6 and ep < 1e-6
