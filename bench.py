@@ -70,6 +70,9 @@ def parse():
                     help="batch workload: per-filter Monte-Carlo traces generated on the device by the simulator kernels "
                          "(default), or one host-made trace per rank replayed by every filter")
     ap.add_argument("--no-pairing", action="store_true", help="one k_update launch per correction (disable k_update2)")
+    ap.add_argument("--tick-pipeline", action="store_true",
+                    help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
+                         "would pick the per-pair kernels (a single filter)")
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
@@ -315,6 +318,8 @@ def main():
         bt.set_deferred(True)
     if args.per_correction or args.no_pairing or args.group:
         bt.set_tick_mode(0)
+    elif args.tick_pipeline:
+        bt.set_tick_mode(1)
     if args.no_pairing:
         bt.set_pairing(False)
     elif args.group:

@@ -58,8 +58,8 @@ struct alignas(16) TickStep {
     int c;                 // first state index of the landmark
     int id;                // resolved id
     double Hc[10], Sinv[4], dz[2], lxy[2];
-    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]
-    double BR[5][kTickNU + 1];     // P_{s-1}(set_s[q], U[p])
+    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]; MP[0][7]: the heading after the correction
+    double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
 };
 
 // Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 
     int cur = 0;
     bool theta_raw = false;               // SM[cur][0] holds theta + K nu of the previous correction, not yet wrapped
+    int last_live = 0;                    // that correction
     for (int st = 0; st < J; ++st) {
         const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
         seen = d.new_seen; brk = d.new_brk; status = d.new_status;
@@ -151,13 +152,13 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         if (d.init) {
             if (wave == 0 && theta_raw) {
                 const double th = normalize_angle(SM[cur][0]);
-                if (lane == 0) SM[cur][0] = th;
+                if (lane == 0) { SM[cur][0] = th; pl[last_live].MP[0][7] = th; }
             }
             lds_barrier();
         }
         if (wave == 0 && theta_raw && !d.init) {
             const double th = normalize_angle(SM[cur][0]);
-            if (lane == 0) SM[cur][0] = th;
+            if (lane == 0) { SM[cur][0] = th; pl[last_live].MP[0][7] = th; }   // the heading row after that correction (:276)
         } else if (wave == 1 || wave == 2) {
             const double x = S0[1], y = S0[2];
             double lx, ly;
@@ -228,16 +229,18 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 #pragma unroll
             for (int q = 0; q < 5; ++q) { MPl[p][q] = m[q]; ps->MP[p][q] = m[q]; }
             MPl[p][5] = bef; MPl[p][6] = aft;
-            ps->MP[p][5] = bef; ps->MP[p][6] = aft; ps->MP[p][7] = 0.0;
+            ps->MP[p][5] = bef; ps->MP[p][6] = aft;
+            if (p > 0) ps->MP[p][7] = 0.0;                              // (MP[0][7]: the wrapped heading, written when it is formed)
             double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : S0[p];
             double acc = 0.0;
             acc = fma(KP[0], dz0, acc);
             acc = fma(KP[1], dz1, acc);
             sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
             SM[cur ^ 1][p] = sv;
-        } else if (tid >= 64 && tid < 64 + 5 * 8) {                     // the five prior rows at the columns of U
-            const int q = (tid - 64) >> 3;
-            for (int p = (tid - 64) & 7; p < NU; p += 8) ps->BR[q][p] = B0[sp[q]][p];
+        } else if (tid >= 64 && tid < 64 + NU) {                        // the five prior rows at the columns of U
+            const int p = tid - 64;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
         } else if (tid == 128) {
             ps->skip = 0; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id;
 #pragma unroll
@@ -259,6 +262,11 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         lds_barrier();
         cur ^= 1;
         theta_raw = true;
+        last_live = st;
+    }
+    if (theta_raw && wave == 0) {                                       // the heading after the last correction
+        const double th = normalize_angle(SM[cur][0]);
+        if (lane == 0) pl[last_live].MP[0][7] = th;
     }
     if (tid == 0) {
         int* co = v.c_out + b * C_WORDS;
@@ -267,99 +275,101 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 }
 
 // ------------------------------------------------------------------------------------------------ the panels
-// 128 threads = 64 state indices x 2 roles: wave 0 owns COLUMN t of the row panel (RP[p] = P(U[p], t)), wave 1 owns ROW t
-// of the column panel (CP[p] = P(t, U[p])) and state entry t.  The whole plan of the round (61 KB) is staged in LDS
-// once; its coefficients are wave-uniform and come back as broadcast ds_reads (scalar loads were tried first: ~60
-// dependent s_load + s_waitcnt per correction made the kernel latency-bound at 4 us per correction).
-// Only the panel entries a later correction still reads are carried: rows / columns 0, 1, 2 and those of the
-// landmarks of LATER markers (a landmark's own rows are consumed at its marker) -- half the work of the full panel.
-constexpr int kPlanWords = (int)(sizeof(TickStep) / 8);
+// 512 threads = 64 state indices x 2 roles x 4 lanes: the four lanes of a QUAD share one index t and split the panel
+// positions p = 4 j + k between them (k = lane & 3).  Role 0 (waves 0-3) carries COLUMN t of the row panel
+// (RP[p] = P(U[p], t)), role 1 (waves 4-7) ROW t of the column panel (CP[p] = P(t, U[p])) and state entry t.
+// Why quads: with one lane per index a wave had 35 dependent coefficient reads per correction and nothing to hide their
+// latency behind (60 % of the wave's cycles parked on lgkmcnt, 2 us per correction); a quarter of the rows per lane and
+// eight waves per workgroup bring it to ~0.3 us.  The five entries every lane of the quad needs (rows / columns
+// set_s) are broadcast inside the quad by DPP.  The plan of the round (61 KB) is staged in LDS once; only the panel
+// entries a later correction still reads are carried (positions 0, 1, 2 and those of LATER markers).
+__device__ inline double quad_bcast(double x, int k)     // lane k of every quad's value to its four lanes; k is a literal
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    switch (k) {                                          // (the DPP control is an immediate)
+    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x55, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x55, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xaa, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xaa, 0xf, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xff, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xff, 0xf, 0xf, false); break;
+    }
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int kQuadRows = (kTickNU + 3) / 4;              // panel positions per lane
 
 template <typename T>
-__global__ __launch_bounds__(128) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
+__global__ __launch_bounds__(512) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                      double* __restrict__ Rbuf)
 {
     constexpr int NU = kTickNU;
     const int b = blockIdx.y;
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int t = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int k = threadIdx.x & 3;                                      // which quarter of the positions
+    const int t = blockIdx.x * 64 + ((threadIdx.x & 255) >> 2);
     const int ld = v.ld, L = v.L;
     const T* Pb = P + (size_t)b * v.p_stride;
     const int J = o.J;
     double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
     double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
 
-    extern __shared__ double plan_l[];                                  // [J][kPlanWords]
+    extern __shared__ double plan_l[];                                  // [J] TickStep
     {
         const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
         Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
         const int n16 = J * (int)(sizeof(TickStep) / 16);
-        for (int e = threadIdx.x; e < n16; e += 128) dst[e] = src[e];
+        for (int e = threadIdx.x; e < n16; e += 512) dst[e] = src[e];
     }
-
-    int U[NU];
-    U[0] = 0; U[1] = 1; U[2] = 2;
+    // this lane's positions p = 4 j + k and the state indices behind them
+    int Uk[kQuadRows];
 #pragma unroll
-    for (int st = 0; st < kTickJ; ++st) {
-        int id = 0;
-        if (st < J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
-        const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
-        U[3 + 2 * st] = c;
-        U[4 + 2 * st] = c + 1;
+    for (int j = 0; j < kQuadRows; ++j) {
+        const int p = 4 * j + k;
+        int u = 3;
+        if (p < 3) u = p;
+        else if (p < NU) {
+            const int st = (p - 3) >> 1;
+            int id = 0;
+            if (st < J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+            u = ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((p - 3) & 1);
+        }
+        Uk[j] = u;
     }
+    const TickStep* pls = reinterpret_cast<const TickStep*>(plan_l);
 
     if (role == 0) {
         // ---- column t of the five-row strips R_s and of the row panel
         const bool live = t < L;
         const T* col = Pb + (size_t)(live ? t : 0) * ld;
-        double RP[NU];
+        double RP[kQuadRows];
 #pragma unroll
-        for (int p = 0; p < NU; ++p) RP[p] = (double)col[U[p]];
+        for (int j = 0; j < kQuadRows; ++j) RP[j] = (double)col[Uk[j]];
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {             // (no break / continue: the loop must unroll, RP is indexed by st)
-            const TickStep* ps = reinterpret_cast<const TickStep*>(plan_l) + (st < J ? st : 0);
+            const TickStep* ps = pls + (st < J ? st : 0);
             if (st < J && !ps->skip) {
                 const int pos = 3 + 2 * st;
-                const double rs[5] = { RP[0], RP[1], RP[2], RP[pos], RP[pos + 1] };   // P_{s-1}(set_s[q], t)
-                if (live) {
+                // P_{s-1}(set_s[q], t): positions 0, 1, 2, pos, pos + 1 live in lanes 0, 1, 2, pos & 3, (pos + 1) & 3
+                const double rs[5] = { quad_bcast(RP[0], 0), quad_bcast(RP[0], 1), quad_bcast(RP[0], 2),
+                                       quad_bcast(RP[pos >> 2], pos & 3), quad_bcast(RP[(pos + 1) >> 2], (pos + 1) & 3) };
+                if (live && k == 0) {
 #pragma unroll
                     for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
                 }
-                // rows 0..2 and the rows of later markers, six at a time: their M rows (wave-uniform, 7 numbers each)
-                // are read together, then the six chains advance stage by stage
 #pragma unroll
-                for (int g = 0; g < (NU + 5) / 6; ++g) {
-                    double mm[6][7], acc[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int pp = 6 * g + k;
-                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                        if (on) {
-#pragma unroll
-                            for (int q = 0; q < 7; ++q) mm[k][q] = ps->MP[pp][q];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int pp = 6 * g + k;
-                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                        if (on) acc[k] = mm[k][0] * rs[0];
-                    }
-#pragma unroll
-                    for (int stg = 1; stg < 7; ++stg)
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            const int pp = 6 * g + k;
-                            const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                            if (on) {
-                                if (stg < 3) acc[k] = fma(mm[k][stg], rs[stg], acc[k]);
-                                else if (stg == 3) acc[k] = fma(mm[k][5], RP[pp], acc[k]);
-                                else if (stg < 6) acc[k] = fma(mm[k][stg - 1], rs[stg - 1], acc[k]);
-                                else RP[pp] = (double)(T)fma(mm[k][6], RP[pp], acc[k]);
-                            }
-                        }
+                for (int j = 0; j < kQuadRows; ++j) {
+                    if (4 * j + 3 < 3 + 0 || (4 * j >= 3 && 4 * j + 3 < pos + 2)) continue;      // no lane of the quad is live here
+                    const int p = 4 * j + k;
+                    const bool on = p < NU && !(p >= 3 && p < pos + 2);  // rows of this and earlier markers are not read again
+                    const int pc = on ? p : 0;
+                    const Pack16<double> m01 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][0]);
+                    const Pack16<double> m23 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][2]);
+                    const Pack16<double> m45 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][4]);
+                    const double m6 = ps->MP[pc][6];
+                    const double m[5] = { m01.v[0], m01.v[1], m23.v[0], m23.v[1], m45.v[0] };
+                    const double nv = p1_entry<T>(m, rs, RP[j], m45.v[1], m6);
+                    RP[j] = on ? nv : RP[j];
                 }
             }
         }
@@ -367,14 +377,14 @@ __global__ __launch_bounds__(128) void k_tick_panels(View v, TickObs o, const T*
         // ---- row t of the gains K_s and of the column panel; state entry t
         const bool live = t < ld;
         const int tr = live ? t : 0;
-        double CP[NU];
+        double CP[kQuadRows];
 #pragma unroll
-        for (int p = 0; p < NU; ++p) CP[p] = (double)Pb[(size_t)U[p] * ld + tr];
+        for (int j = 0; j < kQuadRows; ++j) CP[j] = (double)Pb[(size_t)Uk[j] * ld + tr];
         double sv = v.s_in[(size_t)b * ld + tr];
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {
-            const TickStep* ps = reinterpret_cast<const TickStep*>(plan_l) + (st < J ? st : 0);
+            const TickStep* ps = pls + (st < J ? st : 0);
             const int c = ps->c;
             const bool init = ps->init != 0;
             if (st < J && ps->skip && init) {                           // the landmark was initialised before update() threw
@@ -384,14 +394,15 @@ __global__ __launch_bounds__(128) void k_tick_panels(View v, TickObs o, const T*
             if (st < J && !ps->skip) {
                 const int pos = 3 + 2 * st;
                 const int setv[5] = { 0, 1, 2, c, c + 1 };
-                const double pc[5] = { CP[0], CP[1], CP[2], CP[pos], CP[pos + 1] };   // P_{s-1}(t, set_s[q])
+                const double pc[5] = { quad_bcast(CP[0], 0), quad_bcast(CP[0], 1), quad_bcast(CP[0], 2),
+                                       quad_bcast(CP[pos >> 2], pos & 3), quad_bcast(CP[(pos + 1) >> 2], (pos + 1) & 3) };
                 double Hc[10], Si[4], K[2], m[5];
 #pragma unroll
                 for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
                 gain_row(pc, Hc, Si, t, setv, K, m);
-                if (live) {
+                if (live && k == 0) {
                     Kb[(size_t)(st * 2 + 0) * ld + t] = K[0];
                     Kb[(size_t)(st * 2 + 1) * ld + t] = K[1];
                 }
@@ -401,43 +412,26 @@ __global__ __launch_bounds__(128) void k_tick_panels(View v, TickObs o, const T*
                 acc = fma(K[0], ps->dz[0], acc);
                 acc = fma(K[1], ps->dz[1], acc);
                 s0 = s0 + acc;                                          // :275
-                if (t == 0) s0 = normalize_angle(s0);                   // :276
+                // :276 -- the chain formed exactly this sum for the heading and wrapped it (one wave there instead of a
+                // 450-instruction straggler here, sixteen times)
+                if (t == 0) s0 = ps->MP[0][7];
                 sv = s0;
 #pragma unroll
-                for (int g = 0; g < (NU + 5) / 6; ++g) {  // (as above, for the columns 0..2 and those of later markers)
-                    double rr[6][5], acc[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int pp = 6 * g + k;
-                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                        if (on) {
-#pragma unroll
-                            for (int q = 0; q < 5; ++q) rr[k][q] = ps->BR[q][pp];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int pp = 6 * g + k;
-                        const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                        if (on) acc[k] = m[0] * rr[k][0];
-                    }
-#pragma unroll
-                    for (int stg = 1; stg < 7; ++stg)
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) {
-                            const int pp = 6 * g + k;
-                            const bool on = pp < NU && !(pp >= 3 && pp < pos + 2);
-                            if (on) {
-                                if (stg < 3) acc[k] = fma(m[stg], rr[k][stg], acc[k]);
-                                else if (stg == 3) acc[k] = fma(bef, CP[pp], acc[k]);
-                                else if (stg < 6) acc[k] = fma(m[stg - 1], rr[k][stg - 1], acc[k]);
-                                else CP[pp] = (double)(T)fma(aft, CP[pp], acc[k]);
-                            }
-                        }
+                for (int j = 0; j < kQuadRows; ++j) {
+                    if (4 * j >= 3 && 4 * j + 3 < pos + 2) continue;    // no lane of the quad is live here
+                    const int p = 4 * j + k;
+                    const bool on = p < NU && !(p >= 3 && p < pos + 2);  // columns of this and earlier markers are not read again
+                    const int pcx = on ? p : 0;
+                    const Pack16<double> r01 = *reinterpret_cast<const Pack16<double>*>(&ps->BR[pcx][0]);
+                    const Pack16<double> r23 = *reinterpret_cast<const Pack16<double>*>(&ps->BR[pcx][2]);
+                    const double r4 = ps->BR[pcx][4];
+                    const double r[5] = { r01.v[0], r01.v[1], r23.v[0], r23.v[1], r4 };
+                    const double nv = p1_entry<T>(m, r, CP[j], bef, aft);
+                    CP[j] = on ? nv : CP[j];
                 }
             }
         }
-        if (live) v.s_out[(size_t)b * ld + t] = sv;
+        if (live && k == 0) v.s_out[(size_t)b * ld + t] = sv;
     }
 }
 

@@ -426,7 +426,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T>, dim3(h->B), dim3(256), v, o, total, (const T*)h->P(),
                                    h->tk_plan)));
         if (rc) return rc;
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(128),
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(512),
                                        sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), (const TickStep*)h->tk_plan,
                                        h->tk_K, h->tk_R)));
         if (rc) return rc;
