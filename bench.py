@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--tick-pipeline", action="store_true",
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
+    ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
@@ -320,6 +321,8 @@ def main():
         bt.set_tick_mode(0)
     elif args.tick_pipeline:
         bt.set_tick_mode(1)
+    if args.no_overlap:
+        bt.set_overlap(False)
     if args.no_pairing:
         bt.set_pairing(False)
     elif args.group:
@@ -365,6 +368,7 @@ def main():
     chain_ms, chain_n = bt.profile_read(nh.K_TICK_CHAIN)
     panel_ms, panel_n = bt.profile_read(nh.K_TICK_PANELS)
     apply_ms, apply_n = bt.profile_read(nh.K_TICK_APPLY)
+    next_ms, next_n = bt.profile_read(nh.K_TICK_NEXT)
     bt.profile(False)
     bad, st = bt.status()
     if st != 0:
@@ -488,7 +492,8 @@ def main():
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
         if apply_n:
             out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / max(chain_n, 1), "tick_panels": 1e3 * panel_ms / max(panel_n, 1),
-                                     "tick_apply": 1e3 * apply_ms / apply_n})
+                                     "tick_apply": 1e3 * apply_ms / apply_n,
+                                     "tick_next": 1e3 * next_ms / next_n if next_n else None})
     if args.deferred and flush_n:
         # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved)
         per_launch_bytes = 2.0 * L * L * w * B

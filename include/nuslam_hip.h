@@ -179,6 +179,10 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
  * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
  * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle. */
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
+/* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable != 0 lets the serial chain of tick t+1 run on a
+ * second stream while the strips and the pass over P of tick t run on the handle's (the host knows the next tick's
+ * markers from the resident trace).  Same bits either way; off by default (measured: no gain yet). */
+int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */
 /* The simulator's loop, nuturtlesim/src/tube_world.cpp:509-533, run on the device for every filter of a batch and
@@ -241,7 +245,8 @@ typedef enum {
     NUSLAM_K_TICK_CHAIN = 7,   /* tick pipeline: the serial part of a round of corrections (one workgroup per filter) */
     NUSLAM_K_TICK_PANELS = 8,  /* tick pipeline: the O(len) gain / prior-row strips of the round */
     NUSLAM_K_TICK_APPLY = 9,   /* tick pipeline: the one pass over P that applies the whole round -- the HBM-bound kernel */
-    NUSLAM_K_COUNT = 10
+    NUSLAM_K_TICK_NEXT = 10,   /* tick pipeline, overlapped runs: the next tick's starting block from this tick's plan */
+    NUSLAM_K_COUNT = 11
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

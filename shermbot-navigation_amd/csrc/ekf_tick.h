@@ -62,6 +62,15 @@ struct alignas(16) TickStep {
     double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
 };
 
+// What the chain of the NEXT tick starts from when it runs ahead of the pass over P (nuslam_batch_run on a resident
+// trace): the block and the state at the next tick's index set, after this tick's corrections and the next tick's
+// predict -- formed by k_tick_next from this tick's plan, never read back from the covariance the pass is still writing.
+struct TickHandoff {
+    double BK[kTickNU][kTickNU + 1];
+    double SM[kTickNU + 1];
+    int seen, cached, brk, status;
+};
+
 // Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
 // (__syncthreads() also drains vmcnt, i.e. waits ~1 us for the acknowledgement of every plan store in flight).
 __device__ inline void lds_barrier()
@@ -70,9 +79,10 @@ __device__ inline void lds_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------ the serial chain
-template <typename T>
+template <typename T, bool HANDOFF>
 __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
-                                                    TickStep* __restrict__ plan)
+                                                    TickStep* __restrict__ plan, const TickHandoff* __restrict__ hin,
+                                                    int* __restrict__ ctrl_out4)
 {
     constexpr int NU = kTickNU;
     const int b = blockIdx.x;
@@ -103,11 +113,12 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     }
     if (tid < 3) Ush[tid] = tid;
     __syncthreads();
+    const TickHandoff* hb = hin + b;
     for (int e = tid; e < NU * NU; e += 256) {
         const int p = e / NU, q = e % NU;
-        BK[0][p][q] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+        BK[0][p][q] = HANDOFF ? hb->BK[p][q] : (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
     }
-    if (tid < NU) SM[0][tid] = s[Ush[tid]];
+    if (tid < NU) SM[0][tid] = HANDOFF ? hb->SM[tid] : s[Ush[tid]];
     if (wave == 3 && lane < kTickJ) {             // all markers' polar forms at once, one lane each
         double a = 0.0, bb = 0.0;
         if (lane < J) {
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         zphi[lane] = phi;
     }
     const int* ci = v.c_in + b * C_WORDS;
-    int seen = ci[C_SEEN], brk = ci[C_BRK], status = ci[C_STATUS];
-    const int cached = ci[C_SEEN_CACHED];
+    int seen = HANDOFF ? hb->seen : ci[C_SEEN], brk = HANDOFF ? hb->brk : ci[C_BRK], status = HANDOFF ? hb->status : ci[C_STATUS];
+    const int cached = HANDOFF ? hb->cached : ci[C_SEEN_CACHED];
     __syncthreads();
 
     int cur = 0;
@@ -271,6 +282,208 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     if (tid == 0) {
         int* co = v.c_out + b * C_WORDS;
         co[C_SEEN] = seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = brk; co[C_STATUS] = status;
+        if (ctrl_out4) { int* c4 = ctrl_out4 + 4 * b; c4[0] = seen; c4[1] = cached; c4[2] = brk; c4[3] = status; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the next tick's start
+// P after this tick's corrections and the next tick's predict, restricted to the next tick's index set -- WITHOUT the
+// pass over P having run.  One workgroup per filter carries the block over W = U_t (first 35 positions) U U_{t+1} (last
+// 35) from the covariance the pass will read (after predict(t)) through this tick's plan: H, S^-1, the innovation and
+// the wrapped heading come from the plan (no transcendental here), M at every row of W is gain_row of the block's own
+// entries, and every entry advances by the sweep formula -- the arithmetic of k_tick_chain / k_tick_panels / k_update on
+// those entries.  Then predict(t+1) on the block and the pose exactly as k_predict writes it (slam_library.cpp:65-148).
+constexpr int kNextNW = 2 * kTickNU;
+
+// P(W[p], W[q]) for W = U_t U U_{t+1}, one workgroup per column W[q]: 4900 scattered 8-byte reads are ~16 cycles each
+// through ONE CU's address path (33 us when k_tick_next fetched them itself); spread over 70 CUs they cost a launch.
+// out: [B][NW][NW], out[p * NW + q] = P(W[p], W[q]).
+template <typename T>
+__global__ __launch_bounds__(128) void k_tick_gather(View v, TickObs ot, TickObs on, const T* __restrict__ P,
+                                                     double* __restrict__ out)
+{
+    constexpr int NU = kTickNU, NW = kNextNW;
+    const int b = blockIdx.y, q = blockIdx.x, p = threadIdx.x;
+    auto index_of = [&](int pos) {
+        const TickObs& o = pos < NU ? ot : on;
+        const int pp = pos < NU ? pos : pos - NU;
+        if (pp < 3) return pp;
+        const int st = (pp - 3) >> 1;
+        int id = 0;
+        if (st < o.J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+        return ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((pp - 3) & 1);
+    };
+    if (p >= NW) return;
+    const int wq = index_of(q), wp = index_of(p);
+    out[((size_t)b * NW + p) * NW + q] = (double)P[(size_t)b * v.p_stride + (size_t)wq * v.ld + wp];
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_tick_next(View v, TickObs ot, TickObs on, TwistArg twn, const double* __restrict__ blk,
+                                                    const double* __restrict__ s_after_predict,
+                                                    const TickStep* __restrict__ plan, const int* __restrict__ ctrl4,
+                                                    TickHandoff* __restrict__ hout)
+{
+    constexpr int NU = kTickNU, NW = kNextNW;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ld = v.ld;
+    const double* s = s_after_predict + (size_t)b * ld;
+    extern __shared__ double next_l[];
+    double (*EB0)[NW + 1] = reinterpret_cast<double (*)[NW + 1]>(next_l);
+    double (*EB1)[NW + 1] = reinterpret_cast<double (*)[NW + 1]>(next_l + NW * (NW + 1));
+    double* SMx = next_l + 2 * NW * (NW + 1);                           // [2][NW]
+    double (*MPx)[8] = reinterpret_cast<double (*)[8]>(SMx + 2 * NW);   // [NW][8]
+    double* plan_l = SMx + 2 * NW + 8 * NW;                             // this tick's plan, staged once (the loop below
+    __shared__ int W[NW];                                               // would otherwise chase it through L2 every step)
+    {
+        const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
+        Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
+        const int n16 = ot.J * (int)(sizeof(TickStep) / 16);
+        for (int e = tid; e < n16; e += 1024) dst[e] = src[e];
+    }
+
+    if (tid < 2 * kTickJ) {
+        const TickObs& o = tid < kTickJ ? ot : on;
+        const int st = tid < kTickJ ? tid : tid - kTickJ;
+        int id = 0;
+        if (st < o.J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+        const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
+        const int base = tid < kTickJ ? 0 : NU;
+        W[base + 3 + 2 * st] = c;
+        W[base + 4 + 2 * st] = c + 1;
+    }
+    if (tid < 3) { W[tid] = tid; W[NU + tid] = tid; }
+    __syncthreads();
+    for (int e = tid; e < NW * NW; e += 1024) {
+        const int p = e / NW, q = e % NW;
+        EB0[p][q] = blk[(size_t)b * NW * NW + e];                       // P(W[p], W[q]), gathered by k_tick_gather
+    }
+    if (tid < NW) SMx[tid] = s[W[tid]];
+    __syncthreads();
+
+    int cur = 0;
+    const int J = ot.J;
+    const TickStep* pl = reinterpret_cast<const TickStep*>(plan_l);
+    for (int st = 0; st < J; ++st) {
+        const TickStep* ps = pl + st;
+        const int c = ps->c;
+        const bool init = ps->init != 0;
+        double (*B0)[NW + 1] = cur ? EB1 : EB0;
+        double (*B1)[NW + 1] = cur ? EB0 : EB1;
+        double* S0 = SMx + cur * NW;
+        double* S1 = SMx + (cur ^ 1) * NW;
+        if (ps->skip) {
+            if (init) {                                                 // the landmark was initialised before update() threw
+                if (tid < NW) {
+                    if (W[tid] == c) S0[tid] = ps->lxy[0];
+                    if (W[tid] == c + 1) S0[tid] = ps->lxy[1];
+                }
+                __syncthreads();
+            }
+            continue;
+        }
+        const int pos = 3 + 2 * st;
+        const int sp[5] = { 0, 1, 2, pos, pos + 1 };
+        const int setv[5] = { 0, 1, 2, c, c + 1 };
+        if (tid < NW) {
+            const int p = tid, i = W[p];
+            double pc[5], Hc[10], Si[4], KP[2], m[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
+            gain_row(pc, Hc, Si, i, setv, KP, m);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) MPx[p][q] = m[q];
+            MPx[p][5] = (i > 2 && i < c) ? 1.0 : 0.0;
+            MPx[p][6] = (i > c + 1) ? 1.0 : 0.0;
+            double sv = (init && i == c) ? ps->lxy[0] : (init && i == c + 1) ? ps->lxy[1] : S0[p];
+            double acc = 0.0;
+            acc = fma(KP[0], ps->dz[0], acc);
+            acc = fma(KP[1], ps->dz[1], acc);
+            sv = sv + acc;                                              // :275
+            if (i == 0) sv = ps->MP[0][7];                              // :276, wrapped by the chain
+            S1[p] = sv;
+        }
+        __syncthreads();
+        for (int e = tid; e < NW * NW; e += 1024) {
+            const int p = e / NW, pp = e % NW;
+            // entries whose row or column belongs to this or an earlier marker of tick t are not read again
+            const bool dead = (p >= 3 && p < pos + 2) || (pp >= 3 && pp < pos + 2);
+            if (dead) continue;
+            double mrow[5], r[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { mrow[q] = MPx[p][q]; r[q] = B0[sp[q]][pp]; }
+            B1[p][pp] = p1_entry<T>(mrow, r, B0[p][pp], MPx[p][5], MPx[p][6]);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    double (*BF)[NW + 1] = cur ? EB1 : EB0;
+    double* SF = SMx + cur * NW;
+
+    // ---- predict(t+1) on the block rows / columns of U_{t+1} (positions NU..NW-1), as k_predict does it
+    const double dth = twn.tw ? twn.tw[b * twn.stride + twn.off + 0] : twn.dth0;
+    const double dx = twn.tw ? twn.tw[b * twn.stride + twn.off + 1] : twn.dx0;
+    const double theta = SF[NU];
+    double dq_th, dq_x, dq_y;
+    if (dth == 0.0) {
+        dq_th = 0.0;
+        dq_x = dx * cos(theta);
+        dq_y = dx * sin(theta);
+    } else {
+        dq_th = dth;
+        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
+        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
+    }
+    const double th1 = theta + dq_th;
+    double a1, a2;
+    if (dth == 0) {
+        a1 = -dx * sin(th1);
+        a2 = dx * cos(th1);
+    } else {
+        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
+        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
+    }
+    TickHandoff* ho = hout + b;
+    if (tid < NU) {
+        const int p = tid;
+        ho->SM[p] = p == 0 ? th1 : p == 1 ? SF[NU + 1] + dq_x : p == 2 ? SF[NU + 2] + dq_y : SF[NU + p];
+    }
+    if (tid == 0) {
+        double pp[3][3], tt[3][3], u[3][3];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) pp[i][j] = BF[NU + i][NU + j];
+        for (int j = 0; j < 3; ++j) {
+            tt[0][j] = pp[0][j];
+            tt[1][j] = a1 * pp[0][j] + pp[1][j];
+            tt[2][j] = a2 * pp[0][j] + pp[2][j];
+        }
+        for (int i = 0; i < 3; ++i) {
+            u[i][0] = tt[i][0];
+            u[i][1] = tt[i][0] * a1 + tt[i][1];
+            u[i][2] = tt[i][0] * a2 + tt[i][2];
+        }
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) ho->BK[i][j] = (double)(T)(u[i][j] + v.Q[i + 3 * j]);
+        const int* c4 = ctrl4 + 4 * b;
+        ho->seen = c4[0]; ho->cached = c4[0]; ho->brk = 0; ho->status = c4[3];     // slam.cpp:250-251 at the next tick's top
+    }
+    for (int e = tid; e < NU * NU; e += 1024) {
+        const int p = e / NU, q = e % NU;
+        if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
+        double val = BF[NU + p][NU + q];
+        if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
+            const double p0 = BF[NU + 0][NU + q];
+            val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
+        } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
+            const double t0 = BF[NU + p][NU + 0];
+            val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
+        }
+        ho->BK[p][q] = val;
     }
 }
 

@@ -88,6 +88,13 @@ struct nuslam_batch {
     int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
+    // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
+    // strips and pass of tick t run on the handle's
+    int overlap = 0;           // opt-in (nuslam_batch_set_overlap): bit-identical, but not faster yet -- k_tick_next is ~50 us on
+                               // its one CU and the pass leaves no CU free for the chain to start on
+    hipStream_t stream2 = nullptr;
+    TickStep* tk_plan2 = nullptr; TickHandoff* tk_hand = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
+    std::vector<hipEvent_t> ov_events;
     bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
     int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
     std::vector<int> host_seen;   // host mirror of every filter's `seen`; valid while only known-id calls were made
@@ -140,36 +147,32 @@ hipEvent_t get_event(nuslam_batch* h)
     return e;
 }
 
-// Launch on the handle's stream; with profiling on, the dispatch carries its own start/stop events.
+// Launch on `st` (the handle's stream, or its chain stream); with profiling on, the dispatch carries its own start/stop events.
 template <typename... KArgs, typename... Args>
-int launch(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, Args... args)
+int launch_on(nuslam_batch* h, hipStream_t st, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, Args... args)
 {
     if (h->prof && kid >= 0) {
         hipEvent_t e0 = get_event(h), e1 = get_event(h);
         if (!e0 || !e1) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; }
-        hipExtLaunchKernelGGL(kern, grid, block, 0, h->stream, e0, e1, 0, args...);
+        hipExtLaunchKernelGGL(kern, grid, block, lds, st, e0, e1, 0, args...);
         h->pending[kid].emplace_back(e0, e1);
     } else {
-        hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, args...);
     }
     HIPCHK(hipGetLastError());
     return NUSLAM_OK;
+}
+template <typename... KArgs, typename... Args>
+int launch(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, Args... args)
+{
+    return launch_on(h, h->stream, kid, kern, grid, block, 0, args...);
 }
 
 // the same with dynamic LDS
 template <typename... KArgs, typename... Args>
 int launch_lds(nuslam_batch* h, int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t lds, Args... args)
 {
-    if (h->prof && kid >= 0) {
-        hipEvent_t e0 = get_event(h), e1 = get_event(h);
-        if (!e0 || !e1) { g_hip_err = "hipEventCreate failed"; return NUSLAM_E_HIP; }
-        hipExtLaunchKernelGGL(kern, grid, block, lds, h->stream, e0, e1, 0, args...);
-        h->pending[kid].emplace_back(e0, e1);
-    } else {
-        hipLaunchKernelGGL(kern, grid, block, lds, h->stream, args...);
-    }
-    HIPCHK(hipGetLastError());
-    return NUSLAM_OK;
+    return launch_on(h, h->stream, kid, kern, grid, block, lds, args...);
 }
 
 int drain_profile(nuslam_batch* h)
@@ -387,59 +390,78 @@ bool tick_pipeline_pays(const nuslam_batch* h, int m)
     return h->B >= 2 && m >= 2;
 }
 
-// The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
-// k_tick_panels (the O(len) strips, one thread per state index), k_tick_apply (the one pass over P).
-int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
-                   const double* host_my)
+int ensure_tick_buffers(nuslam_batch* h)
 {
-    if (!h->tk_plan) {
-        const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-        HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
-        HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
-        HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * (size_t)h->B * kTickJ * 5 * h->ld));
+    if (h->tk_plan) return NUSLAM_OK;
+    const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
+    HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
+    HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * (size_t)h->B * kTickJ * 5 * h->ld));
+    return NUSLAM_OK;
+}
+
+TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, const int* host_ids, const double* host_mx,
+                      const double* host_my)
+{
+    TickObs o;
+    o.J = (m - i0) < kTickJ ? (m - i0) : kTickJ;
+    o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
+    o.ids = host_ids ? nullptr : base.ids;
+    o.stride = base.stride; o.off = base.off + i0;
+    o.cartesian = base.cartesian;
+    o.log_slot0 = h->id_log ? i0 : -1;
+    for (int k = 0; k < kTickJ; ++k) {
+        const bool in = k < o.J;
+        o.a0[k] = (in && host_mx) ? host_mx[i0 + k] : (in ? base.a0 : 0.0);
+        o.b0[k] = (in && host_my) ? host_my[i0 + k] : (in ? base.b0 : 0.0);
+        o.id0[k] = (in && host_ids) ? host_ids[i0 + k] : (in ? base.id0 : 0);
     }
+    return o;
+}
+
+// strips + the pass over P of one round, on the handle's stream, from `plan`
+int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan)
+{
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     const int waves = sweep_waves(h, vec, strips);
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(512),
+                                   sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
+    if (rc) return rc;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
+    const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
+    if (waves == 8)
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, o.J, plan,
+                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
+    else
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, o.J, plan,
+                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
+    return rc;
+}
+
+// The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
+// k_tick_panels (the O(len) strips, one quad per state index), k_tick_apply (the one pass over P).
+int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
+                   const double* host_my)
+{
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
     for (int i0 = 0; i0 < m; i0 += kTickJ) {
-        TickObs o;
-        o.J = (m - i0) < kTickJ ? (m - i0) : kTickJ;
-        o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
-        o.ids = host_ids ? nullptr : base.ids;
-        o.stride = base.stride; o.off = base.off + i0;
-        o.cartesian = base.cartesian;
-        o.log_slot0 = h->id_log ? i0 : -1;
-        for (int k = 0; k < kTickJ; ++k) {
-            const bool in = k < o.J;
-            o.a0[k] = (in && host_mx) ? host_mx[i0 + k] : (in ? base.a0 : 0.0);
-            o.b0[k] = (in && host_my) ? host_my[i0 + k] : (in ? base.b0 : 0.0);
-            o.id0[k] = (in && host_ids) ? host_ids[i0 + k] : (in ? base.id0 : 0);
-        }
+        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my);
         View v = h->view();
         int rc = NUSLAM_OK;
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T>, dim3(h->B), dim3(256), v, o, total, (const T*)h->P(),
-                                   h->tk_plan)));
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
+                                   (const T*)h->P(), h->tk_plan, (const TickHandoff*)nullptr, (int*)nullptr)));
         if (rc) return rc;
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(512),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), (const TickStep*)h->tk_plan,
-                                       h->tk_K, h->tk_R)));
-        if (rc) return rc;
-        dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
-        const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
-        if (waves == 8)
-            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, o.J,
-                                           (const TickStep*)h->tk_plan, (const double*)h->tk_K, (const double*)h->tk_R,
-                                           (const T*)h->P(), (T*)h->Palt())));
-        else
-            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, o.J,
-                                           (const TickStep*)h->tk_plan, (const double*)h->tk_K, (const double*)h->tk_R,
-                                           (const T*)h->P(), (T*)h->Palt())));
+        rc = launch_strips_and_pass(h, v, o, h->tk_plan);
         if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
@@ -518,19 +540,121 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     return NUSLAM_OK;
 }
 
+// nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
+// tick's markers while it enqueues this one.  Two streams:
+//   handle's stream   predict(t) -> [chain(t) done] -> strips(t) -> pass(t)            (touches P and the state vector)
+//   chain stream      chain(t) -> [predict(t) done] -> next(t) -> chain(t+1) -> ...    (touches a 35 x 35 block)
+// chain(t+1) starts from the hand-off k_tick_next(t) forms out of plan(t) and the covariance pass(t) READS, so it runs
+// while strips(t) / pass(t) / predict(t+1) run.  Same arithmetic, same bits as the one-stream order
+// (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
+int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
+{
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    if (!h->stream2) {
+        // its own hardware queue, served first: a chain is one workgroup per filter and must not queue behind the
+        // pass's 256 (two plain streams of one process can share a hardware queue, which would serialise the two)
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * (size_t)h->B * kTickJ));
+        HIPCHK(hipMalloc(&h->tk_hand, sizeof(TickHandoff) * (size_t)h->B));
+        HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * (size_t)h->B));
+        HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * (size_t)h->B * kNextNW * kNextNW));
+    }
+    const int n = t_end - t_begin;
+    while ((int)h->ov_events.size() < 4 * n) {            // per tick: predict, chain, next, pass
+        hipEvent_t e = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));   // device-scope ordering only: no L2 write-back to the host per event
+        h->ov_events.push_back(e);
+    }
+    auto ev = [&](int t, int which) { return h->ov_events[(size_t)4 * (t - t_begin) + which]; };
+    enum { E_PRED = 0, E_CHAIN = 1, E_NEXT = 2, E_PASS = 3 };
+    auto obs_of = [&](int t) {
+        ObsArg o;
+        o.a = h->tr_mx; o.b = h->tr_my; o.ids = h->tr_ids;
+        o.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * h->tr_m;
+        o.off = (long long)t * h->tr_m;
+        o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
+        const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
+        return make_tick_obs(h, o, 0, h->tr_m, hid, nullptr, nullptr);
+    };
+    auto twist_of = [&](int t) {
+        TwistArg tw;
+        tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
+        tw.dth0 = tw.dx0 = 0.0;
+        return tw;
+    };
+    // the chain stream starts behind everything already enqueued on the handle's stream
+    HIPCHK(hipEventRecord(ev(t_begin, E_PASS), h->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream2, ev(t_begin, E_PASS), 0));
+    for (int t = t_begin; t < t_end; ++t) {
+        TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
+        // ---- handle's stream: predict(t); it overwrites the state buffer next(t-1) reads
+        if (t > t_begin) HIPCHK(hipStreamWaitEvent(h->stream, ev(t - 1, E_NEXT), 0));
+        int rc = do_predict(h, twist_of(t));
+        if (rc) return rc;
+        if (t + 1 < t_end) {
+            // the block k_tick_next(t) starts from, out of the covariance pass(t) will read (70 workgroups, 70 columns)
+            const View vg = h->view();
+            DISPATCH_T(h, rc = (launch(h, -1, k_tick_gather<T>, dim3(kNextNW, h->B), dim3(128), vg, obs_of(t), obs_of(t + 1),
+                                       (const T*)h->P(), h->tk_blk)));
+            if (rc) return rc;
+        }
+        HIPCHK(hipEventRecord(ev(t, E_PRED), h->stream));
+        // ---- chain stream: chain(t) (from P for the first tick, from the hand-off afterwards), then next(t)
+        const TickObs o = obs_of(t);
+        const View v = h->view();
+        if (t - 2 >= t_begin) HIPCHK(hipStreamWaitEvent(h->stream2, ev(t - 2, E_PASS), 0));   // this plan buffer was pass(t-2)'s
+        if (t == t_begin) {
+            HIPCHK(hipStreamWaitEvent(h->stream2, ev(t, E_PRED), 0));
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
+                                          total, (const T*)h->P(), plan, (const TickHandoff*)nullptr, h->tk_ctrl4)));
+        } else {
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256), 0, v, o,
+                                          total, (const T*)h->P(), plan, (const TickHandoff*)h->tk_hand, h->tk_ctrl4)));
+        }
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev(t, E_CHAIN), h->stream2));
+        if (t + 1 < t_end) {
+            HIPCHK(hipStreamWaitEvent(h->stream2, ev(t, E_PRED), 0));
+            const size_t lds = sizeof(double) * (2 * (size_t)kNextNW * (kNextNW + 1) + 2 * kNextNW + 8 * kNextNW) +
+                               sizeof(TickStep) * (size_t)o.J;
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(1024), lds, v, o, obs_of(t + 1),
+                                          twist_of(t + 1), (const double*)h->tk_blk, (const double*)h->state[h->sidx],
+                                          (const TickStep*)plan, (const int*)h->tk_ctrl4, h->tk_hand)));
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(ev(t, E_NEXT), h->stream2));
+        }
+        // ---- handle's stream: strips(t) and the pass over P
+        HIPCHK(hipStreamWaitEvent(h->stream, ev(t, E_CHAIN), 0));
+        if (getenv("NUSLAM_SERIALIZE_NEXT") && t + 1 < t_end) HIPCHK(hipStreamWaitEvent(h->stream, ev(t, E_NEXT), 0));   // experiment
+        rc = launch_strips_and_pass(h, v, o, plan);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(ev(t, E_PASS), h->stream));
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+        h->pidx ^= 1;
+    }
+    h->host_seen_valid = false;
+    h->last_tick = t_end - 1;
+    return NUSLAM_OK;
+}
+
 void free_batch(nuslam_batch* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (int k = 0; k < NUSLAM_K_COUNT; ++k)
         for (auto& pr : h->pending[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
+    for (auto e : h->ov_events) (void)hipEventDestroy(e);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1027,6 +1151,13 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
     int* saved_log = h->id_log;
     h->id_log = nullptr;  // resident traces do not log resolved ids
     int rc = NUSLAM_OK;
+    const bool known_trace = h->tr_ids != nullptr && !h->tr_presence_only;
+    if (h->overlap && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
+        (h->tick_mode != 0) && (h->tr_bcast ? !h->h_ids.empty() : true)) {     // (auto: with the chains overlapped the pipeline pays for one filter too)
+        rc = run_overlapped(h, t_begin, t_end, total_landmarks);
+        h->id_log = saved_log;
+        return rc;
+    }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
         tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
@@ -1129,6 +1260,13 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
     if (!h || mode < -1 || mode > 1) return NUSLAM_E_ARG;
     h->tick_mode = mode;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    h->overlap = enable != 0;
     return NUSLAM_OK;
 }
 

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY, E_COMM = range(9)
 COMM_ID_BYTES = 128
 F64, F32 = 0, 1
-K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2, K_TICK_CHAIN, K_TICK_PANELS, K_TICK_APPLY = range(10)
+K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2, K_TICK_CHAIN, K_TICK_PANELS, K_TICK_APPLY, K_TICK_NEXT = range(11)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -66,6 +66,7 @@ SYMBOLS = [
     ("nuslam_ekf_set_deferred", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_pairing", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_tick_mode", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_set_overlap", C.c_int, [_vp, C.c_int]),
     ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
@@ -391,6 +392,9 @@ class Batch:
     def set_tick_mode(self, mode):
         """1 (default): known-id ticks as chain + panels + ONE pass over P; 0: one pass per correction / pair."""
         _chk(lib().nuslam_batch_set_tick_mode(self._h, int(mode)), "batch_set_tick_mode")
+
+    def set_overlap(self, enable=True):
+        _chk(lib().nuslam_batch_set_overlap(self._h, 1 if enable else 0), "batch_set_overlap")
 
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")

@@ -113,3 +113,38 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
     es, ep = rel(fs[0].state, o.state), rel(P0, o.cov)
     print("N=1000 tick pipeline: == pair kernel == single kernel bitwise; vs oracle state %.2e cov %.2e" % (es, ep))
     assert es < 1e-6 and ep < 1e-6
+
+
+@pytest.mark.parametrize("B,n,m,dtype,cold", [(1, 40, 16, 0, False), (3, 30, 5, 0, False), (4, 20, 16, 1, False), (2, 12, 8, 0, True)])
+def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold):
+    """nuslam_batch_run with the chain of tick t+1 running ahead on its own stream (k_tick_next forms its starting block
+    from tick t's plan) against the one-stream order: same state, covariance, seen, status -- warm, through first
+    sightings (cold), with skipped markers and a straight tick (dth == 0) in the trace, fp64 and fp32 storage."""
+    T = 7
+    traces = [synth.make_trace(n, T, m, seed=400 + k, straight_every=3) for k in range(B)]
+    tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces])
+    my = np.stack([t.my for t in traces]); ids = np.stack([t.ids for t in traces]).copy()
+    ids[:, 2, 1] = -1                                            # a skipped marker in tick 2
+    if m > 2:
+        ids[:, 4, 2] = ids[:, 4, 0]                              # the same landmark twice in tick 4
+    res = []
+    for overlap in (True, False):
+        bt = hip.Batch(B, n, Q, R, dtype=dtype)
+        bt.set_tick_mode(1)
+        bt.set_overlap(overlap)
+        if not cold:
+            bx, by, wid = synth.warmup_observations(traces[0].landmarks)
+            bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+            bt.run(0, 1)
+        if B == 1:
+            bt.load_trace(tw[0], mx[0], my[0], ids[0], bcast=True)
+        else:
+            bt.load_trace(tw, mx, my, ids)
+        bt.run(0, 3)                                             # two runs: the hand-off chain restarts from memory
+        bt.run(3, T)
+        assert bt.status() == (-1, 0)
+        res.append([(bt.state(k), bt.cov(k), bt.seen(k)) for k in range(B)])
+    for k in range(B):
+        assert np.array_equal(res[0][k][0], res[1][k][0]), "state of filter %d" % k
+        assert np.array_equal(res[0][k][1], res[1][k][1]), "covariance of filter %d" % k
+        assert res[0][k][2] == res[1][k][2]
