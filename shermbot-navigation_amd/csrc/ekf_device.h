@@ -74,7 +74,9 @@ struct TwistArg {
 
 __device__ inline double normalize_angle(double rad)       // rigid2d/src/rigid2d.cpp:9-13
 {
-    return atan2(sin(rad), cos(rad));
+    double sn, cs;
+    sincos(rad, &sn, &cs);          // one argument reduction for both (same values as sin(rad), cos(rad))
+    return atan2(sn, cs);
 }
 
 __device__ inline void cartesian2polar(double x, double y, double& r, double& b) // slam_library.cpp:16-22

@@ -79,6 +79,9 @@ __device__ inline void lds_barrier()
 }
 
 // ------------------------------------------------------------------------------------------------ the serial chain
+#ifdef NUSLAM_CHAIN_CLOCK
+__device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
+#endif
 template <typename T, bool HANDOFF>
 __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
                                                     TickStep* __restrict__ plan, const TickHandoff* __restrict__ hin,
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 
     __shared__ double BK[2][NU][NU + 1];          // P(U[p], U[p']) before / after the current correction
     __shared__ double SM[2][NU + 1];              // state at U
-    __shared__ double MPl[NU][8];
+    __shared__ double MPl[2][NU][8];              // M at the rows of U: of the correction in flight / of the one whose block update is pending
     __shared__ double zr[kTickJ], zphi[kTickJ];   // the markers in polar form (slam.cpp:286)
     __shared__ double hd[20];                     // Hc[10], Sinv[4], lx, ly, dz0, dz1, z_hat range, un-rotated bearing
     __shared__ int hi[2];
@@ -115,7 +118,9 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     __syncthreads();
     const TickHandoff* hb = hin + b;
     for (int e = tid; e < NU * NU; e += 256) {
-        const int p = e / NU, q = e % NU;
+        // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
+        // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
+        const int q = e / NU, p = e % NU;
         BK[0][p][q] = HANDOFF ? hb->BK[p][q] : (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
     }
     if (tid < NU) SM[0][tid] = HANDOFF ? hb->SM[tid] : s[Ush[tid]];
@@ -136,10 +141,44 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     const int cached = HANDOFF ? hb->cached : ci[C_SEEN_CACHED];
     __syncthreads();
 
-    int cur = 0;
-    bool theta_raw = false;               // SM[cur][0] holds theta + K nu of the previous correction, not yet wrapped
+    // The block update of correction s is DEFERRED into the first phase of correction s+1, where it runs on waves 0, 2, 3
+    // in the shadow of wave 1's transcendental chain (the polar form of the next landmark offset needs the state, not
+    // the block).  Wave 2 forms the 25 entries the next head needs itself, with the same formula.
+    auto advance_entry = [&](const double (*Bo)[NU + 1], const double (*Mp)[8], const int spP[5], int p, int pp) {
+        double mrow[5], r[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { mrow[q] = Mp[p][q]; r[q] = Bo[spP[q]][pp]; }
+        return p1_entry<T>(mrow, r, Bo[p][pp], Mp[p][5], Mp[p][6]);
+    };
+    // entries of the deferred update: shared by the 192 lanes of waves 0, 2, 3 (or by all 256 in the serial path)
+    auto run_pending = [&](const double (*Bo)[NU + 1], double (*Bn)[NU + 1], const double (*Mp)[8], int posP, int me) {
+        // only the rows / columns a later correction still reads: positions 0, 1, 2 and those behind marker posP (the
+        // same liveness as in the strips), walked as a 16 x 12 thread grid over the live index list -- no division
+        const int spP[5] = { 0, 1, 2, posP, posP + 1 };
+        if (me < 0) return;
+        const int nl = 3 + (NU - (posP + 2));
+        const int ty = me / 12, tx = me - 12 * ty;
+        for (int a = ty; a < nl; a += 16) {
+            const int p = a < 3 ? a : posP + 2 + (a - 3);
+            for (int c2 = tx; c2 < nl; c2 += 12) {
+                const int pp = c2 < 3 ? c2 : posP + 2 + (c2 - 3);
+                Bn[p][pp] = advance_entry(Bo, Mp, spP, p, pp);
+            }
+        }
+    };
+    int bcur = 0, scur = 0, mb = 0;
+    bool pend = false;                    // BK[bcur] still lacks the update of correction `last_live` (MPl[mb], position pend_pos)
+    int pend_pos = 3;
+    bool theta_raw = false;               // SM[scur][0] holds theta + K nu of the previous correction, not yet wrapped
     int last_live = 0;                    // that correction
+#ifdef NUSLAM_CHAIN_CLOCK
+    long long ck[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ct = (long long)wall_clock64();
+#define CK(k) do { const long long n__ = (long long)wall_clock64(); ck[k] += n__ - ct; ct = n__; } while (0)
+#else
+#define CK(k) do { } while (0)
+#endif
     for (int st = 0; st < J; ++st) {
+        CK(7);
         const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
         seen = d.new_seen; brk = d.new_brk; status = d.new_status;
         TickStep* ps = pl + st;
@@ -151,26 +190,28 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         const int pos = 3 + 2 * st, c = d.c;
         const int sp[5] = { 0, 1, 2, pos, pos + 1 };                    // positions of set_s in U
         const int setv[5] = { 0, 1, 2, c, c + 1 };
-        double (*B0)[NU + 1] = BK[cur];
-        double (*B1)[NU + 1] = BK[cur ^ 1];
-        const double* S0 = SM[cur];
 
-        // ---- three chains side by side.  The heading left by the previous correction is still the raw sum
-        // theta + K nu; its re-normalisation (:276: sin, cos, atan2) runs on wave 0 WHILE wave 1 turns the landmark
-        // offset into polar form (the first half of computeTheoreticalMeasurement, :150-158: sqrt, atan2, sin, cos,
-        // atan2 -- none of which reads the heading) and wave 2 forms H, S, S^-1 (which do not read it either).  Only a
-        // first sighting needs the heading first (initializeLandmark, :255-261).
         if (d.init) {
+            // A first sighting needs the wrapped heading before anything else (initializeLandmark, :255-261): serial path
             if (wave == 0 && theta_raw) {
-                const double th = normalize_angle(SM[cur][0]);
-                if (lane == 0) { SM[cur][0] = th; pl[last_live].MP[0][7] = th; }
+                const double th = normalize_angle(SM[scur][0]);
+                if (lane == 0) { SM[scur][0] = th; pl[last_live].MP[0][7] = th; }
             }
+            if (pend) run_pending(BK[bcur], BK[bcur ^ 1], MPl[mb], pend_pos, wave == 0 ? -1 : tid - 64);
             lds_barrier();
+            if (pend) { bcur ^= 1; pend = false; }
+            theta_raw = false;
         }
-        if (wave == 0 && theta_raw && !d.init) {
-            const double th = normalize_angle(SM[cur][0]);
-            if (lane == 0) { SM[cur][0] = th; pl[last_live].MP[0][7] = th; }   // the heading row after that correction (:276)
-        } else if (wave == 1 || wave == 2) {
+        const double (*Bo)[NU + 1] = BK[bcur];                          // the block before the pending update (if any)
+        const double* S0 = SM[scur];
+
+        // ---- phase 1: heading re-normalisation (wave 0) | polar form of the landmark offset (wave 1) | H, S, S^-1
+        // (wave 2) | the deferred block update (waves 0, 2, 3)
+        if (wave == 0 && theta_raw) {
+            const double th = normalize_angle(SM[scur][0]);
+            if (lane == 0) { SM[scur][0] = th; pl[last_live].MP[0][7] = th; }   // the heading row after that correction (:276)
+        }
+        if (wave == 1 || wave == 2) {
             const double x = S0[1], y = S0[2];
             double lx, ly;
             if (d.init) {                                               // initializeLandmark, slam_library.cpp:255-261
@@ -179,11 +220,21 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
                 ly = y + r * sin(phi + th);
             } else { lx = S0[pos]; ly = S0[pos + 1]; }
             if (wave == 2) {
+                // P(set[q2], set[q]) after the pending update: formed here, one entry per lane, then broadcast
+                double ent = 0.0;
+                {
+                    const int e = lane < 25 ? lane : 0;
+                    const int q = e / 5, q2 = e % 5;
+                    if (pend) {
+                        const int spP[5] = { 0, 1, 2, pend_pos, pend_pos + 1 };
+                        ent = advance_entry(Bo, MPl[mb], spP, sp[q2], sp[q]);
+                    } else ent = Bo[sp[q2]][sp[q]];
+                }
                 double Hc[10], S[4], Si[4], pb[5][5];
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
 #pragma unroll
-                    for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = B0[sp[q2]][sp[q]];       // pb[q][q2] = P(set[q2], set[q])
+                    for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);   // pb[q][q2] = P(set[q2], set[q])
                 jacobian_compact(x, y, lx, ly, Hc);                     // :268
                 innovation_cov_block(pb, Hc, v.R, S);                   // H P H^T + R, :270
                 const int sing = inv2(S, Si);
@@ -202,33 +253,33 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
                 if (lane == 0) { hd[18] = zr_h; hd[19] = zb_h; }
             }
         }
+        if (pend) {
+            // measured per correction (wave clock): head 1.05 us on wave 2, heading 0.6 us on wave 0, polar form 1.0 us on
+            // wave 1 -- so wave 3 takes two thirds of the deferred update, wave 0 the rest, wave 2 none
+            if (wave == 0) run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, lane);
+            else if (wave == 3) {
+                run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, 64 + lane);
+                run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, 128 + lane);
+            }
+        }
         theta_raw = false;
+        CK(0);
         lds_barrier();
-        if (wave == 1) {
-            const double zb = normalize_angle(hd[19] - S0[0]);          // :157-159, the heading now re-normalised
-            if (lane == 0) { hd[16] = zr[st] - hd[18]; hd[17] = zphi[st] - zb; }        // :272, bearing not wrapped
-        }
-        lds_barrier();
-        const double lx = hd[14], ly = hd[15];
-        if (hi[0]) {                                                    // singular S: update() throws after the init
-            if (status == 0) status = kStatusSingular;
-            if (tid == 0) {
-                ps->skip = 1; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
-            }
-            if (d.init && tid < NU) {
-                const int i = Ush[tid];
-                if (i == c) SM[cur][tid] = lx;
-                if (i == c + 1) SM[cur][tid] = ly;
-            }
-            lds_barrier();
-            continue;
-        }
-        const double dz0 = hd[16], dz1 = hd[17];
+        CK(1);
+        if (pend) { bcur ^= 1; pend = false; }
+        const double (*B0)[NU + 1] = BK[bcur];                          // the block before THIS correction, complete
 
-        // ---- K and M at the rows of U (one row per thread), the state at U, and the plan of this correction
-        if (tid < NU) {
+        // ---- phase 2: the bearing against the wrapped heading (wave 1) | K, M at the rows of U (wave 0), the prior
+        // rows at the columns of U (wave 2)
+        const double lx = hd[14], ly = hd[15];
+        const bool sing = hi[0] != 0;
+        double KP[2] = { 0.0, 0.0 };
+        if (wave == 1) {
+            const double zb = normalize_angle(hd[19] - S0[0]);          // :157-159
+            if (lane == 0) { hd[16] = zr[st] - hd[18]; hd[17] = zphi[st] - zb; }        // :272, bearing not wrapped
+        } else if (!sing && tid < NU) {
             const int p = tid, i = Ush[p];
-            double pc[5], Hc[10], Si[4], KP[2], m[5];
+            double pc[5], Hc[10], Si[4], m[5];
 #pragma unroll
             for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];          // P(U[p], set[q])
 #pragma unroll
@@ -237,21 +288,43 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             for (int q = 0; q < 4; ++q) Si[q] = hd[10 + q];
             gain_row(pc, Hc, Si, i, setv, KP, m);
             const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
+            double (*Mn)[8] = MPl[mb ^ 1];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { MPl[p][q] = m[q]; ps->MP[p][q] = m[q]; }
-            MPl[p][5] = bef; MPl[p][6] = aft;
+            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; ps->MP[p][q] = m[q]; }
+            Mn[p][5] = bef; Mn[p][6] = aft;
             ps->MP[p][5] = bef; ps->MP[p][6] = aft;
             if (p > 0) ps->MP[p][7] = 0.0;                              // (MP[0][7]: the wrapped heading, written when it is formed)
+        } else if (!sing && tid >= 128 && tid < 128 + NU) {             // the five prior rows at the columns of U
+            const int p = tid - 128;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
+        }
+        CK(2);
+        lds_barrier();
+        CK(3);
+        if (sing) {                                                     // singular S: update() throws after the init
+            if (status == 0) status = kStatusSingular;
+            if (tid == 0) {
+                ps->skip = 1; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
+            }
+            if (d.init && tid < NU) {
+                const int i = Ush[tid];
+                if (i == c) SM[scur][tid] = lx;
+                if (i == c + 1) SM[scur][tid] = ly;
+            }
+            lds_barrier();
+            continue;
+        }
+        // ---- phase 3: the state at U (wave 0) and the scalars of the plan
+        const double dz0 = hd[16], dz1 = hd[17];
+        if (tid < NU) {
+            const int p = tid, i = Ush[p];
             double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : S0[p];
             double acc = 0.0;
             acc = fma(KP[0], dz0, acc);
             acc = fma(KP[1], dz1, acc);
             sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
-            SM[cur ^ 1][p] = sv;
-        } else if (tid >= 64 && tid < 64 + NU) {                        // the five prior rows at the columns of U
-            const int p = tid - 64;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
+            SM[scur ^ 1][p] = sv;
         } else if (tid == 128) {
             ps->skip = 0; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id;
 #pragma unroll
@@ -260,23 +333,22 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
             ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
         }
+        CK(4);
         lds_barrier();
-
-        // ---- the block after this correction
-        for (int e = tid; e < NU * NU; e += 256) {
-            const int p = e / NU, pp = e % NU;
-            double mrow[5], r[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { mrow[q] = MPl[p][q]; r[q] = B0[sp[q]][pp]; }
-            B1[p][pp] = p1_entry<T>(mrow, r, B0[p][pp], MPl[p][5], MPl[p][6]);
-        }
-        lds_barrier();
-        cur ^= 1;
+        CK(5);
+        scur ^= 1;
+        mb ^= 1;
+        pend = true;
+        pend_pos = pos;
         theta_raw = true;
         last_live = st;
     }
+#ifdef NUSLAM_CHAIN_CLOCK
+    if (lane == 0 && b == 0)
+        for (int k = 0; k < 8; ++k) g_chain_clock[wave * 8 + k] = ck[k];
+#endif
     if (theta_raw && wave == 0) {                                       // the heading after the last correction
-        const double th = normalize_angle(SM[cur][0]);
+        const double th = normalize_angle(SM[scur][0]);
         if (lane == 0) pl[last_live].MP[0][7] = th;
     }
     if (tid == 0) {
@@ -510,16 +582,18 @@ __device__ inline double quad_bcast(double x, int k)     // lane k of every quad
 
 constexpr int kQuadRows = (kTickNU + 3) / 4;              // panel positions per lane
 
-template <typename T>
-__global__ __launch_bounds__(512) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
+// IDX = state indices per workgroup (64: 8 waves; 32: 4 waves, one per SIMD -- the kernel is VALU-issue-bound, so a single
+// filter, whose 2003 indices fill only a fraction of the chip anyway, takes the smaller groups on twice the CUs).
+template <typename T, int IDX>
+__global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                      double* __restrict__ Rbuf)
 {
     constexpr int NU = kTickNU;
     const int b = blockIdx.y;
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (IDX * 4));
     const int k = threadIdx.x & 3;                                      // which quarter of the positions
-    const int t = blockIdx.x * 64 + ((threadIdx.x & 255) >> 2);
+    const int t = blockIdx.x * IDX + ((threadIdx.x % (IDX * 4)) >> 2);
     const int ld = v.ld, L = v.L;
     const T* Pb = P + (size_t)b * v.p_stride;
     const int J = o.J;
@@ -531,7 +605,7 @@ __global__ __launch_bounds__(512) void k_tick_panels(View v, TickObs o, const T*
         const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
         Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
         const int n16 = J * (int)(sizeof(TickStep) / 16);
-        for (int e = threadIdx.x; e < n16; e += 512) dst[e] = src[e];
+        for (int e = threadIdx.x; e < n16; e += IDX * 8) dst[e] = src[e];
     }
     // this lane's positions p = 4 j + k and the state indices behind them
     int Uk[kQuadRows];

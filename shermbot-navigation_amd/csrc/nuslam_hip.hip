@@ -381,13 +381,13 @@ int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, 
 }
 
 // The tick pipeline moves P once per tick instead of once per pair of corrections, at the price of a serial chain
-// (~3 us per correction, one workgroup per filter) and the strip kernel.  With many filters those run side by side and
-// the pass over P dominates: measured 1.8x at 1024 x N = 200.  For ONE filter the chain is exposed (N = 1000: 130 us
-// per tick against 121 us for eight pair launches) until chain and pass of consecutive ticks overlap.
+// (~2.4 us per correction, one workgroup per filter) and the strip kernel.  With many filters those run side by side and
+// the pass over P dominates (measured 2x at 1024 x N = 200); for ONE filter the chain is exposed and the gain is
+// smaller (N = 1000, 16 markers: 105 us per tick against 121 us for eight pair launches).
 bool tick_pipeline_pays(const nuslam_batch* h, int m)
 {
     if (h->tick_mode >= 0) return h->tick_mode == 1;
-    return h->B >= 2 && m >= 2;
+    return m >= 4;                                  // (fewer markers: the fixed cost of three launches is not recovered)
 }
 
 int ensure_tick_buffers(nuslam_batch* h)
@@ -398,8 +398,10 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
@@ -434,8 +436,12 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     const int waves = sweep_waves(h, vec, strips);
     int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T>, dim3((h->ld + 63) / 64, h->B), dim3(512),
-                                   sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
+    if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
+    else
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, h->B), dim3(512),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
     if (rc) return rc;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
@@ -1185,6 +1191,14 @@ int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const do
     return restore(h, b, state, cov, ld, seen);
 }
 
+#ifdef NUSLAM_CHAIN_CLOCK
+extern "C" int nuslam_debug_chain_clock(long long out[32])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_chain_clock), sizeof(long long) * 32));
+    return NUSLAM_OK;
+}
+#endif
 #ifdef NUSLAM_PHASE_CLOCK
 extern "C" int nuslam_debug_phase(long long out[32])
 {

@@ -29,6 +29,7 @@ def warm_pair_of_filters(hip, n, dtype=0, seed=12345, group=2):
     for pairing in (True, False):
         g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
         g.restore(o.state, o.cov, n)
+        g.as_batch().set_tick_mode(0)                    # these tests are about the per-pair kernels
         g.as_batch().set_pairing(group if pairing else 0)
         gs.append(g)
     return o, gs[0], gs[1], lm
@@ -136,6 +137,7 @@ def test_pair_batch_and_full_size(hip):
     res = []
     for pairing in (4, False, 2):
         bt = hip.Batch(B, n, Q, R)
+        bt.set_tick_mode(0)
         bt.set_pairing(pairing)
         bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], ids[None, :], bcast=True)
         bt.run(0, 1)
@@ -152,6 +154,7 @@ def test_pair_batch_and_full_size(hip):
     out = []
     for pairing in (4, False):
         g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+        g.as_batch().set_tick_mode(0)
         g.as_batch().set_pairing(pairing)
         g.tick(np.zeros(3), bx, by, known_ids=ids, want_ids=False)
         for t in range(2):
@@ -178,6 +181,7 @@ def test_pair_with_per_filter_ids_in_resident_trace(hip):
     res = []
     for pairing in (True, False):
         bt = hip.Batch(B, n, Q, R)
+        bt.set_tick_mode(0)
         bt.set_pairing(pairing)
         bt.load_trace(tw, mx, my, ids)
         bt.profile(True)
@@ -188,6 +192,7 @@ def test_pair_with_per_filter_ids_in_resident_trace(hip):
         bt.profile(False)
         # finish initialising every landmark in every filter, then replay the rest of the per-filter traces
         bt2 = hip.Batch(B, n, Q, R)
+        bt2.set_tick_mode(0)
         bt2.set_pairing(pairing)
         bt2.load_trace(np.zeros((1, 2)), bx[None], by[None], wid[None], bcast=True)
         bt2.run(0, 1)
@@ -218,6 +223,7 @@ def test_four_wave_groups_when_the_grid_exceeds_one_generation(hip, dtype):
     res = []
     for pairing in (True, False):
         bt = hip.Batch(B, n, Q, R, dtype=dtype)
+        bt.set_tick_mode(0)
         bt.set_pairing(pairing)
         bt.load_trace(np.zeros((1, 2)), bx[None], by[None], wid[None], bcast=True)
         bt.run(0, 1)

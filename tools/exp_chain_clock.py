@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Where does a k_tick_chain step spend its time?  NUSLAM_HIP_LIB = a -DNUSLAM_CHAIN_CLOCK build."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
+import nuslam_hip as nh
+from nuslam_hip import synth
+n, m = 1000, 16
+tr = synth.make_trace(n, 40, m)
+bx, by, wid = synth.warmup_observations(tr.landmarks)
+ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT)
+ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+bt = ekf.as_batch(); bt.set_tick_mode(1)
+bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+bt.run(0, 30); bt.sync()
+L = nh.lib(); L.nuslam_debug_chain_clock.argtypes = [C.POINTER(C.c_longlong)]
+acc = []
+for t in range(30, 40):
+    bt.run(t, t + 1); bt.sync()
+    out = (C.c_longlong * 32)(); L.nuslam_debug_chain_clock(out); acc.append(list(out))
+a = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8) * 0.01 / m   # us per step
+names = ["phase 1", "barrier 1", "phase 2", "barrier 2", "phase 3", "barrier 3", "-", "loop top"]
+for w in range(4):
+    print("wave %d: " % w + ", ".join("%s %.2f" % (names[k], a[w, k]) for k in (7, 0, 1, 2, 3, 4, 5)) + "  | sum %.2f us/step" % a[w].sum())
