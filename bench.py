@@ -74,6 +74,7 @@ def parse():
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
+    ap.add_argument("--overlap", action="store_true", help="opt-in: the chain of tick t+1 on a second stream (nuslam_batch_set_overlap)")
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
@@ -323,6 +324,8 @@ def main():
         bt.set_tick_mode(1)
     if args.no_overlap:
         bt.set_overlap(False)
+    if args.overlap:
+        bt.set_overlap(True)
     if args.no_pairing:
         bt.set_pairing(False)
     elif args.group:

@@ -32,7 +32,7 @@ template <typename T>
 __device__ inline Pack16<T> load_stream(const T* p)
 {
     typedef T vt __attribute__((ext_vector_type(16 / sizeof(T))));
-#if defined(NUSLAM_NO_STREAM) || defined(NUSLAM_LOAD_PLAIN)
+#ifdef NUSLAM_NO_STREAM
     const vt y = *reinterpret_cast<const vt*>(p);
 #else
     const vt y = __builtin_nontemporal_load(reinterpret_cast<const vt*>(p));
@@ -49,11 +49,7 @@ __device__ inline void store_stream(T* p, const Pack16<T>& x)
     vt y;
 #pragma unroll
     for (int e = 0; e < (int)(16 / sizeof(T)); ++e) y[e] = x.v[e];
-#if defined(NUSLAM_STORE_SC1)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(y) : "memory");   // write-through, line dropped from L2
-#elif defined(NUSLAM_STORE_SC01)
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(y) : "memory");
-#elif defined(NUSLAM_NO_STREAM) || defined(NUSLAM_STORE_PLAIN)
+#ifdef NUSLAM_NO_STREAM
     *reinterpret_cast<vt*>(p) = y;
 #else
     __builtin_nontemporal_store(y, reinterpret_cast<vt*>(p));
@@ -87,8 +83,9 @@ __global__ __launch_bounds__(256) void k_init(View v, const double* __restrict__
 // STATE_ONLY: predictEstimate + the tick bookkeeping only; the covariance is then propagated by the dense MFMA
 // path (nuslam_ekf_predict_dense) instead of the two-non-zero shortcut below.
 template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restrict__ P)
+__global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restrict__ P, int bookkeeping)
 {
+    // bookkeeping == 0: the control words are carried by the chain stream (overlapped runs), this kernel leaves them alone
     const int b = blockIdx.z;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const double* s = v.s_in + (size_t)b * v.ld;
@@ -121,7 +118,7 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
     if (t < v.ld) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
 
     if (STATE_ONLY) {
-        if (t == 0) {
+        if (t == 0 && bookkeeping) {
             const int* ci = v.c_in + b * C_WORDS;
             int* co = v.c_out + b * C_WORDS;
             co[C_SEEN] = ci[C_SEEN]; co[C_SEEN_CACHED] = ci[C_SEEN]; co[C_BRK] = 0; co[C_STATUS] = ci[C_STATUS];
@@ -149,12 +146,14 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
             for (int i = 0; i < 3; ++i) Pb[(size_t)j * ld + i] = (T)(u[i][j] + v.Q[i + 3 * j]);
         // slam.cpp:250-251: the caller caches seen_landmarks at the top of the loop body; a new tick also
         // clears the `break` of the previous marker loop.
-        const int* ci = v.c_in + b * C_WORDS;
-        int* co = v.c_out + b * C_WORDS;
-        co[C_SEEN] = ci[C_SEEN];
-        co[C_SEEN_CACHED] = ci[C_SEEN];
-        co[C_BRK] = 0;
-        co[C_STATUS] = ci[C_STATUS];
+        if (bookkeeping) {
+            const int* ci = v.c_in + b * C_WORDS;
+            int* co = v.c_out + b * C_WORDS;
+            co[C_SEEN] = ci[C_SEEN];
+            co[C_SEEN_CACHED] = ci[C_SEEN];
+            co[C_BRK] = 0;
+            co[C_STATUS] = ci[C_STATUS];
+        }
     } else if (t >= 3 && t < v.L) {
         T* col = Pb + (size_t)t * ld;               // column role: rows 1,2 of column t
         const double p0 = (double)col[0];

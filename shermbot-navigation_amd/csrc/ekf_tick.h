@@ -78,6 +78,43 @@ __device__ inline void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Hand-offs BETWEEN kernels of the two streams of an overlapped run (nuslam_batch_set_overlap): a monotonic counter in
+// global memory, agent scope.  Producer: every workgroup, after a barrier behind all its stores, one thread: release
+// fence, drain, add.  Consumer: one thread polls (bounded), acquire fence (this CU's L1 may hold the buffer's lines of
+// two ticks ago), drain, workgroup barrier -- the forms of cdna_hip_programming.md Guideline 16.  Waiting is bounded:
+// if the producer never arrives the consumer gives up after ~0.2 s and the results are flagged through `ok`.
+__device__ inline void tick_signal(int* cnt)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool tick_wait(const int* cnt, int target)      // every thread of the workgroup calls it
+{
+    __shared__ int ok_sh;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < (1 << 18); ++it) {
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok_sh = ok;
+    }
+    __syncthreads();
+    return ok_sh != 0;
+}
+
+// The consumer side as a kernel of its own (one wave): the kernel enqueued behind it on the same stream starts when the
+// counter has arrived, and starts with the usual kernel-boundary acquire.  (The wait used to sit at the top of
+// k_tick_panels: the mere presence of the agent-scope fence in that kernel, never executed in one-stream runs, took it
+// from 20 to 37 us.)
+__global__ __launch_bounds__(64) void k_tick_wait(const int* __restrict__ cnt, int target, int* __restrict__ timeouts)
+{
+    if (!tick_wait(cnt, target) && threadIdx.x == 0) atomicAdd(timeouts, 1);
+}
+
 // ------------------------------------------------------------------------------------------------ the serial chain
 #ifdef NUSLAM_CHAIN_CLOCK
 __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
@@ -85,7 +122,7 @@ __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz
 template <typename T, bool HANDOFF>
 __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
                                                     TickStep* __restrict__ plan, const TickHandoff* __restrict__ hin,
-                                                    int* __restrict__ ctrl_out4)
+                                                    int* __restrict__ ctrl_out4, int* __restrict__ done_cnt)
 {
     constexpr int NU = kTickNU;
     const int b = blockIdx.x;
@@ -356,151 +393,140 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         co[C_SEEN] = seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = brk; co[C_STATUS] = status;
         if (ctrl_out4) { int* c4 = ctrl_out4 + 4 * b; c4[0] = seen; c4[1] = cached; c4[2] = brk; c4[3] = status; }
     }
+    if (done_cnt) {                                                     // overlapped runs: the plan is complete
+        __syncthreads();
+        if (tid == 0) tick_signal(done_cnt);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the next tick's start
-// P after this tick's corrections and the next tick's predict, restricted to the next tick's index set -- WITHOUT the
-// pass over P having run.  One workgroup per filter carries the block over W = U_t (first 35 positions) U U_{t+1} (last
-// 35) from the covariance the pass will read (after predict(t)) through this tick's plan: H, S^-1, the innovation and
-// the wrapped heading come from the plan (no transcendental here), M at every row of W is gain_row of the block's own
-// entries, and every entry advances by the sweep formula -- the arithmetic of k_tick_chain / k_tick_panels / k_update on
-// those entries.  Then predict(t+1) on the block and the pose exactly as k_predict writes it (slam_library.cpp:65-148).
-constexpr int kNextNW = 2 * kTickNU;
+// P after this tick's corrections and the next tick's predict, restricted to the next tick's index set U' = U_{t+1} --
+// WITHOUT waiting for the pass over P.  Correction s changes entry (a, b) of that 35 x 35 block through K_s(U'[a], :) and
+// R_s(:, U'[b]) only, and those are numbers k_tick_panels produces anyway (it forms K_s for every row and R_s for every
+// column); it drops the ones at U' into compact arrays (a position map says which threads own them), and k_tick_next
+// replays the sixteen corrections on the block from the covariance the pass will READ (gathered by k_tick_prep), then
+// predict(t+1) exactly as k_predict writes it (slam_library.cpp:65-148).  Same arithmetic on every entry as the pass
+// itself.  (First version: a 70 x 70 block carried with its own gain rows -- 50-60 us on one CU, as long as the chain.)
 
-// P(W[p], W[q]) for W = U_t U U_{t+1}, one workgroup per column W[q]: 4900 scattered 8-byte reads are ~16 cycles each
-// through ONE CU's address path (33 us when k_tick_next fetched them itself); spread over 70 CUs they cost a launch.
-// out: [B][NW][NW], out[p * NW + q] = P(W[p], W[q]).
+// behind predict(t) on the handle's stream: the position map of U' (posmap[i] = first position of state index i in U',
+// else -1; the entries set for the previous tick's map -- U_t -- are cleared first) and the block P(U'[p], U'[q]).
 template <typename T>
-__global__ __launch_bounds__(128) void k_tick_gather(View v, TickObs ot, TickObs on, const T* __restrict__ P,
-                                                     double* __restrict__ out)
+__global__ __launch_bounds__(64) void k_tick_prep(View v, TickObs ot, TickObs on, const T* __restrict__ P,
+                                                  int* __restrict__ posmap, double* __restrict__ blk)
 {
-    constexpr int NU = kTickNU, NW = kNextNW;
+    constexpr int NU = kTickNU;
     const int b = blockIdx.y, q = blockIdx.x, p = threadIdx.x;
-    auto index_of = [&](int pos) {
-        const TickObs& o = pos < NU ? ot : on;
-        const int pp = pos < NU ? pos : pos - NU;
-        if (pp < 3) return pp;
-        const int st = (pp - 3) >> 1;
+    auto index_of = [&](const TickObs& o, int pos) {
+        if (pos < 3) return pos;
+        const int st = (pos - 3) >> 1;
         int id = 0;
         if (st < o.J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
-        return ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((pp - 3) & 1);
+        return ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((pos - 3) & 1);
     };
-    if (p >= NW) return;
-    const int wq = index_of(q), wp = index_of(p);
-    out[((size_t)b * NW + p) * NW + q] = (double)P[(size_t)b * v.p_stride + (size_t)wq * v.ld + wp];
+    if (q < NU) {
+        if (p < NU) blk[((size_t)b * NU + p) * NU + q] = (double)P[(size_t)b * v.p_stride + (size_t)index_of(on, q) * v.ld + index_of(on, p)];
+        return;
+    }
+    int* pm = posmap + (size_t)b * v.ld;                                // the last workgroup of the row: the map
+    if (p < NU) pm[index_of(ot, p)] = -1;
+    __syncthreads();
+    if (p == 0)
+        for (int k = NU - 1; k >= 0; --k) pm[index_of(on, k)] = k;      // descending: the FIRST position of an index stays
 }
 
 template <typename T>
-__global__ __launch_bounds__(1024) void k_tick_next(View v, TickObs ot, TickObs on, TwistArg twn, const double* __restrict__ blk,
-                                                    const double* __restrict__ s_after_predict,
-                                                    const TickStep* __restrict__ plan, const int* __restrict__ ctrl4,
-                                                    TickHandoff* __restrict__ hout)
+__global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg twn, int Jt, const double* __restrict__ blk,
+                                                   const double* __restrict__ KU, const double* __restrict__ RU,
+                                                   const double* __restrict__ SU, const TickStep* __restrict__ plan,
+                                                   const int* __restrict__ ctrl4, TickHandoff* __restrict__ hout,
+                                                   int* __restrict__ done_cnt)
 {
-    constexpr int NU = kTickNU, NW = kNextNW;
+    constexpr int NU = kTickNU, NE = (NU * NU + 255) / 256;             // entries per thread
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const int ld = v.ld;
-    const double* s = s_after_predict + (size_t)b * ld;
-    extern __shared__ double next_l[];
-    double (*EB0)[NW + 1] = reinterpret_cast<double (*)[NW + 1]>(next_l);
-    double (*EB1)[NW + 1] = reinterpret_cast<double (*)[NW + 1]>(next_l + NW * (NW + 1));
-    double* SMx = next_l + 2 * NW * (NW + 1);                           // [2][NW]
-    double (*MPx)[8] = reinterpret_cast<double (*)[8]>(SMx + 2 * NW);   // [NW][8]
-    double* plan_l = SMx + 2 * NW + 8 * NW;                             // this tick's plan, staged once (the loop below
-    __shared__ int W[NW];                                               // would otherwise chase it through L2 every step)
-    {
-        const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
-        Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
-        const int n16 = ot.J * (int)(sizeof(TickStep) / 16);
-        for (int e = tid; e < n16; e += 1024) dst[e] = src[e];
-    }
+    const TickStep* pl = plan + (size_t)b * kTickJ;
 
-    if (tid < 2 * kTickJ) {
-        const TickObs& o = tid < kTickJ ? ot : on;
-        const int st = tid < kTickJ ? tid : tid - kTickJ;
+    __shared__ double KUl[kTickJ][2][NU + 1];
+    __shared__ double RUl[kTickJ][5][NU + 1];
+    __shared__ double PS[kTickJ][12];             // Hc[10], c, skip
+    __shared__ double FB[NU][NU + 1];
+    __shared__ double SF[NU + 1];
+    __shared__ int U[NU + 1], canon[NU + 1];
+
+    if (tid < kTickJ) {
         int id = 0;
-        if (st < o.J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+        if (tid < on.J) id = on.ids ? on.ids[b * on.stride + on.off + tid] : on.id0[tid];
         const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
-        const int base = tid < kTickJ ? 0 : NU;
-        W[base + 3 + 2 * st] = c;
-        W[base + 4 + 2 * st] = c + 1;
+        U[3 + 2 * tid] = c;
+        U[4 + 2 * tid] = c + 1;
     }
-    if (tid < 3) { W[tid] = tid; W[NU + tid] = tid; }
+    if (tid < 3) U[tid] = tid;
+    for (int e = tid; e < kTickJ * 12; e += 256) {
+        const int st = e / 12, f = e % 12;
+        const TickStep* ps = pl + (st < Jt ? st : 0);
+        PS[st][f] = f < 10 ? ps->Hc[f] : (f == 10 ? (double)ps->c : (double)(st < Jt ? ps->skip : 1));
+    }
     __syncthreads();
-    for (int e = tid; e < NW * NW; e += 1024) {
-        const int p = e / NW, q = e % NW;
-        EB0[p][q] = blk[(size_t)b * NW * NW + e];                       // P(W[p], W[q]), gathered by k_tick_gather
+    if (tid < NU) {                                                     // the position whose strips stand for this one
+        int cp = tid;
+        for (int k = tid - 1; k >= 0; --k)
+            if (U[k] == U[tid]) cp = k;
+        canon[tid] = cp;
     }
-    if (tid < NW) SMx[tid] = s[W[tid]];
+    __syncthreads();
+    // the strips at U' (compact, written by k_tick_panels through the position map) and the state there
+    for (int e = tid; e < kTickJ * 2 * NU; e += 256) {
+        const int st = e / (2 * NU), r = (e / NU) % 2, p = e % NU;
+        KUl[st][r][p] = KU[(((size_t)b * kTickJ + st) * 2 + r) * NU + canon[p]];
+    }
+    for (int e = tid; e < kTickJ * 5 * NU; e += 256) {
+        const int st = e / (5 * NU), q = (e / NU) % 5, p = e % NU;
+        RUl[st][q][p] = RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + canon[p]];
+    }
+    if (tid < NU) SF[tid] = SU[(size_t)b * NU + canon[tid]];
+    int ea[NE], eb[NE];
+    double E[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = tid + 256 * k;
+        ea[k] = e < NU * NU ? e / NU : -1;
+        eb[k] = e < NU * NU ? e % NU : 0;
+        E[k] = e < NU * NU ? blk[(size_t)b * NU * NU + e] : 0.0;
+    }
     __syncthreads();
 
-    int cur = 0;
-    const int J = ot.J;
-    const TickStep* pl = reinterpret_cast<const TickStep*>(plan_l);
-    for (int st = 0; st < J; ++st) {
-        const TickStep* ps = pl + st;
-        const int c = ps->c;
-        const bool init = ps->init != 0;
-        double (*B0)[NW + 1] = cur ? EB1 : EB0;
-        double (*B1)[NW + 1] = cur ? EB0 : EB1;
-        double* S0 = SMx + cur * NW;
-        double* S1 = SMx + (cur ^ 1) * NW;
-        if (ps->skip) {
-            if (init) {                                                 // the landmark was initialised before update() threw
-                if (tid < NW) {
-                    if (W[tid] == c) S0[tid] = ps->lxy[0];
-                    if (W[tid] == c + 1) S0[tid] = ps->lxy[1];
-                }
-                __syncthreads();
+    for (int st = 0; st < Jt; ++st) {
+        const double* ps = PS[st];
+        if (ps[11] != 0.0) continue;                                    // (a skipped marker moves nothing in P)
+        const int c = (int)ps[10];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            if (ea[k] < 0) continue;
+            const int i = U[ea[k]];
+            const double K0 = KUl[st][0][ea[k]], K1 = KUl[st][1][ea[k]];
+            double m[5], r[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                double kh = 0.0;                                        // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+                kh = fma(K0, ps[0 + 2 * q], kh);
+                kh = fma(K1, ps[1 + 2 * q], kh);
+                const int sidx = q < 3 ? q : c + (q - 3);
+                m[q] = (i == sidx ? 1.0 : 0.0) - kh;
+                r[q] = RUl[st][q][eb[k]];
             }
-            continue;
+            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
+            E[k] = p1_entry<T>(m, r, E[k], bef, aft);
         }
-        const int pos = 3 + 2 * st;
-        const int sp[5] = { 0, 1, 2, pos, pos + 1 };
-        const int setv[5] = { 0, 1, 2, c, c + 1 };
-        if (tid < NW) {
-            const int p = tid, i = W[p];
-            double pc[5], Hc[10], Si[4], KP[2], m[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];
-#pragma unroll
-            for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
-            gain_row(pc, Hc, Si, i, setv, KP, m);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) MPx[p][q] = m[q];
-            MPx[p][5] = (i > 2 && i < c) ? 1.0 : 0.0;
-            MPx[p][6] = (i > c + 1) ? 1.0 : 0.0;
-            double sv = (init && i == c) ? ps->lxy[0] : (init && i == c + 1) ? ps->lxy[1] : S0[p];
-            double acc = 0.0;
-            acc = fma(KP[0], ps->dz[0], acc);
-            acc = fma(KP[1], ps->dz[1], acc);
-            sv = sv + acc;                                              // :275
-            if (i == 0) sv = ps->MP[0][7];                              // :276, wrapped by the chain
-            S1[p] = sv;
-        }
-        __syncthreads();
-        for (int e = tid; e < NW * NW; e += 1024) {
-            const int p = e / NW, pp = e % NW;
-            // entries whose row or column belongs to this or an earlier marker of tick t are not read again
-            const bool dead = (p >= 3 && p < pos + 2) || (pp >= 3 && pp < pos + 2);
-            if (dead) continue;
-            double mrow[5], r[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { mrow[q] = MPx[p][q]; r[q] = B0[sp[q]][pp]; }
-            B1[p][pp] = p1_entry<T>(mrow, r, B0[p][pp], MPx[p][5], MPx[p][6]);
-        }
-        __syncthreads();
-        cur ^= 1;
     }
-    double (*BF)[NW + 1] = cur ? EB1 : EB0;
-    double* SF = SMx + cur * NW;
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+        if (ea[k] >= 0) FB[ea[k]][eb[k]] = E[k];
+    __syncthreads();
 
-    // ---- predict(t+1) on the block rows / columns of U_{t+1} (positions NU..NW-1), as k_predict does it
+    // ---- predict(t+1) on the block and the pose, as k_predict does it (slam_library.cpp:65-148)
     const double dth = twn.tw ? twn.tw[b * twn.stride + twn.off + 0] : twn.dth0;
     const double dx = twn.tw ? twn.tw[b * twn.stride + twn.off + 1] : twn.dx0;
-    const double theta = SF[NU];
+    const double theta = SF[0];
     double dq_th, dq_x, dq_y;
     if (dth == 0.0) {
         dq_th = 0.0;
@@ -523,12 +549,12 @@ __global__ __launch_bounds__(1024) void k_tick_next(View v, TickObs ot, TickObs 
     TickHandoff* ho = hout + b;
     if (tid < NU) {
         const int p = tid;
-        ho->SM[p] = p == 0 ? th1 : p == 1 ? SF[NU + 1] + dq_x : p == 2 ? SF[NU + 2] + dq_y : SF[NU + p];
+        ho->SM[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
     }
     if (tid == 0) {
         double pp[3][3], tt[3][3], u[3][3];
         for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) pp[i][j] = BF[NU + i][NU + j];
+            for (int i = 0; i < 3; ++i) pp[i][j] = FB[i][j];
         for (int j = 0; j < 3; ++j) {
             tt[0][j] = pp[0][j];
             tt[1][j] = a1 * pp[0][j] + pp[1][j];
@@ -544,19 +570,21 @@ __global__ __launch_bounds__(1024) void k_tick_next(View v, TickObs ot, TickObs 
         const int* c4 = ctrl4 + 4 * b;
         ho->seen = c4[0]; ho->cached = c4[0]; ho->brk = 0; ho->status = c4[3];     // slam.cpp:250-251 at the next tick's top
     }
-    for (int e = tid; e < NU * NU; e += 1024) {
+    for (int e = tid; e < NU * NU; e += 256) {
         const int p = e / NU, q = e % NU;
         if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
-        double val = BF[NU + p][NU + q];
+        double val = FB[p][q];
         if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
-            const double p0 = BF[NU + 0][NU + q];
+            const double p0 = FB[0][q];
             val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
         } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
-            const double t0 = BF[NU + p][NU + 0];
+            const double t0 = FB[p][0];
             val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
         }
         ho->BK[p][q] = val;
     }
+    __syncthreads();
+    if (tid == 0) tick_signal(done_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ the panels
@@ -587,8 +615,11 @@ constexpr int kQuadRows = (kTickNU + 3) / 4;              // panel positions per
 template <typename T, int IDX>
 __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
-                                                     double* __restrict__ Rbuf)
+                                                     double* __restrict__ Rbuf, const int* __restrict__ posmap,
+                                                     double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
 {
+    // posmap != null (overlapped runs): the strips at the NEXT tick's index set are also dropped into the compact arrays
+    // KU [J][2][NU], RU [J][5][NU], SU [NU] (state after the round) for k_tick_next
     constexpr int NU = kTickNU;
     const int b = blockIdx.y;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (IDX * 4));
@@ -627,6 +658,7 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
     if (role == 0) {
         // ---- column t of the five-row strips R_s and of the row panel
         const bool live = t < L;
+        const int pm = (posmap && live && k == 0) ? posmap[(size_t)b * ld + t] : -1;
         const T* col = Pb + (size_t)(live ? t : 0) * ld;
         double RP[kQuadRows];
 #pragma unroll
@@ -643,6 +675,10 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
                 if (live && k == 0) {
 #pragma unroll
                     for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
+                }
+                if (pm >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + pm] = rs[q];
                 }
 #pragma unroll
                 for (int j = 0; j < kQuadRows; ++j) {
@@ -664,6 +700,7 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
         // ---- row t of the gains K_s and of the column panel; state entry t
         const bool live = t < ld;
         const int tr = live ? t : 0;
+        const int pm = (posmap && live && k == 0) ? posmap[(size_t)b * ld + t] : -1;
         double CP[kQuadRows];
 #pragma unroll
         for (int j = 0; j < kQuadRows; ++j) CP[j] = (double)Pb[(size_t)Uk[j] * ld + tr];
@@ -693,6 +730,10 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
                     Kb[(size_t)(st * 2 + 0) * ld + t] = K[0];
                     Kb[(size_t)(st * 2 + 1) * ld + t] = K[1];
                 }
+                if (pm >= 0) {
+                    KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + pm] = K[0];
+                    KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + pm] = K[1];
+                }
                 const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
                 double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;
                 double acc = 0.0;
@@ -719,6 +760,7 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
             }
         }
         if (live && k == 0) v.s_out[(size_t)b * ld + t] = sv;
+        if (pm >= 0) SU[(size_t)b * NU + pm] = sv;
     }
 }
 

@@ -94,9 +94,6 @@ enum { S2_HC1 = 0, S2_SI1 = 10, S2_HC2 = 14, S2_SI2 = 24, S2_M1S = 28 /* [a][q] 
        S2_OBS = 85 /* r1, phi1, r2, phi2 */, S2_K1S = 89 /* [a][2]: K1(set2[a], :) */, S2_NU1 = 100 /* z1 - z_hat1 */,
        S2_ZH2 = 102 /* range and un-rotated bearing of z_hat2 */, S2_WORDS = 104 };
 
-#ifdef NUSLAM_EXP_WARM
-__device__ double g_exp_heads[128];
-#endif
 template <typename T, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsArg o1, ObsArg o2, const T* __restrict__ Pin,
                                                  T* __restrict__ Pout)
@@ -122,26 +119,16 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
     const int role = wave;   // (rotation tried and measured: no gain)
     // Column strip 0 is half as wide as the others (8 columns): its wave also carries the state rows and, in workgroup
     // (0,0), the heading's second re-normalisation; with a full tile it was the last wave of every launch to finish.
-#ifdef NUSLAM_EXP_FULLSTRIP0
-    const int jstart = strip * CW;
-#else
     const int jstart = strip == 0 ? 0 : strip * CW - CW / 2;
-#endif
     const bool active = jstart < L;
     const int j0 = active ? jstart : 0;
     const bool rows_ok = row0 < ld;
     const int rowc = rows_ok ? row0 : 0;
-#ifdef NUSLAM_EXP_FULLSTRIP0
-    const int wcol = CW;
-#else
     const int wcol = strip == 0 ? CW / 2 : CW;
-#endif
     const int ncol = (L - j0) < wcol ? (L - j0) : wcol;
 
-#ifndef NUSLAM_EXP_WARM
     __shared__ double sh[S2_WORDS];
     __shared__ int sh_i[4];                       // singular flag of correction 1, of correction 2, status
-#endif
     PHASE(0);
 #ifdef NUSLAM_PHASE_CLOCK
     if (threadIdx.x == 0 && blockIdx.z == 0) g_wg[blockIdx.y * gridDim.x + blockIdx.x][0] = (long long)wall_clock64();
@@ -191,13 +178,6 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
         load_obs_raw(w2 ? o2.a : o1.a, w2 ? o2.b : o1.b, w2 ? o2.stride : o1.stride, w2 ? o2.off : o1.off,   // would put them on the stack
                      w2 ? o2.a0 : o1.a0, w2 ? o2.b0 : o1.b0, b, s, raw_a, raw_b);
     }
-#ifdef NUSLAM_EXP_WARM
-#ifdef NUSLAM_EXP_NOSCRATCH
-    const double h0 = 0.125 * lane, h1 = 0.0625 * lane;
-#else
-    const double h0 = g_exp_heads[lane], h1 = g_exp_heads[lane < S2_WORDS - 64 ? 64 + lane : 0];
-#endif
-#endif
 #ifndef NUSLAM_NO_GATE
     // Gate: nothing bulky is requested before these few values are back.  All 512 workgroups are resident at once and
     // the memory system serves requests roughly in arrival order, so without the gate the later-dispatched half of the
@@ -211,12 +191,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
     const int sj = lane & 15, sq = lane >> 4;
     const int sjc = sj < ncol ? sj : 0;
     const T* colp = Pb + (size_t)(j0 + sjc) * ld;
-#ifdef NUSLAM_EXP_NOSTRIP
-    const double vA = 0.25 * lane, vB = 0.5 * lane;
-#else
     const double vA = (double)colp[sq < 3 ? sq : c1];
     const double vB = (double)colp[sq == 0 ? c1 + 1 : (sq == 1 ? c2 : c2 + 1)];
-#endif
     vec_t pcU[7];                                  // columns U[k] of P0 at this lane's rows
 #pragma unroll
     for (int k = 0; k < 7; ++k) pcU[k] = *reinterpret_cast<const vec_t*>(Pb + (size_t)U[k] * ld + rowc);
@@ -228,34 +204,6 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
     for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
     PHASE(12);
 
-#ifdef NUSLAM_EXP_WARM
-    // TIMING EXPERIMENT ONLY (never the product): the heads come from a global scratch image instead of the two-phase
-    // chain -- what a launch would cost if the previous launch had prepared them.
-    __shared__ double shw[WAVES][S2_WORDS];
-    {
-        shw[wave][lane] = h0;
-        if (lane < S2_WORDS - 64) shw[wave][64 + lane] = h1;
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-    }
-#define sh shw[wave]
-    int sing1 = 0;
-    if (!active) return;
-    const int sing2 = 0;
-    const double* Hc1 = sh + S2_HC1; const double* Si1 = sh + S2_SI1;
-    const double* Hc2 = sh + S2_HC2; const double* Si2 = sh + S2_SI2;
-    const double dz10 = sh[S2_NU1], dz11 = sh[S2_NU1 + 1];
-    const bool owns_state = (strip == 0);
-    double dz20 = 0.0, dz21 = 0.0;
-    if (owns_state && !sing2) {
-        const double zb = normalize_angle(sh[S2_ZH2 + 1] - sh[S2_ST1]);
-        dz20 = sh[S2_OBS + 2] - sh[S2_ZH2];
-        dz21 = sh[S2_OBS + 3] - zb;
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        int* co = v.c_out + b * C_WORDS;
-        co[C_SEEN] = seen_in; co[C_SEEN_CACHED] = cached_in; co[C_BRK] = brk_in; co[C_STATUS] = status_in;
-    }
-#else
     // ---- phase A, four roles in parallel (the transcendental chains need the state and the trace only, not P):
     //   role 1: marker 1 in polar form      role 2: marker 2 in polar form      role 3: z_hat of correction 1
     //   role 0: head of correction 1 (H1, S1^-1) and K1 / M1 at the rows of set2
@@ -428,18 +376,8 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
         if (v.id_log && o2.log_slot >= 0) v.id_log[(size_t)b * v.log_stride + o2.log_slot] = id2;
     }
 
-#endif
     // ---- this lane's rows: M1, then the columns set2 of P1 at these rows, then M2
     double m1[VEC][5], m2[VEC][5], bef1[VEC], aft1[VEC], bef2[VEC], aft2[VEC];
-#ifdef NUSLAM_EXP_NOROWS
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-#pragma unroll
-        for (int q = 0; q < 5; ++q) { m1[e][q] = (double)pcU[q].v[e]; m2[e][q] = (double)pcU[q + 2].v[e]; }
-        bef1[e] = aft1[e] = bef2[e] = aft2[e] = 0.0;
-    }
-    if (0)
-#endif
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const int i = row0 + e;
@@ -521,13 +459,9 @@ __global__ __launch_bounds__(64 * WAVES, 8 / WAVES) void k_update2(View v, ObsAr
         vec_t out;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-#ifdef NUSLAM_EXP_NOSWEEP
-            out.v[e] = p[jj].v[e];
-#else
             // k_update stores P1 in T; with fp32 storage the second correction must start from that rounded value
             const double p1 = p1_entry<T>(m1[e], r1v, (double)p[jj].v[e], bef1[e], aft1[e]);
             out.v[e] = (T)sweep_entry(m2[e], r2v, p1, bef2[e], aft2[e]);
-#endif
         }
         if (jj < ncol && rows_ok) store_stream(Pw + (size_t)jj * ld, out);
     };

@@ -90,10 +90,15 @@ struct nuslam_batch {
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
+    int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
     int overlap = 0;           // opt-in (nuslam_batch_set_overlap): bit-identical, but not faster yet -- k_tick_next is ~50 us on
                                // its one CU and the pass leaves no CU free for the chain to start on
     hipStream_t stream2 = nullptr;
     TickStep* tk_plan2 = nullptr; TickHandoff* tk_hand = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
+    int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
+    int* tk_posmap = nullptr; double* tk_KU = nullptr; double* tk_RU = nullptr; double* tk_SU = nullptr;
+    int seq_chain = 0, seq_next = 0;                   // the counters' values after everything enqueued so far
+    hipEvent_t ov_start = nullptr;
     std::vector<hipEvent_t> ov_events;
     bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
     int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
@@ -239,10 +244,10 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
     if (h->dense_predict) {
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, true>, grid, block, v, tw, (T*)h->P())));
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, true>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping)));
         if (!rc) rc = launch_dense(h);
     } else {
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, v, tw, (T*)h->P())));
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping)));
     }
     if (rc) return rc;
     h->sidx ^= 1;
@@ -402,8 +407,6 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<double>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_next<float>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
     HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
     HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * (size_t)h->B * kTickJ * 5 * h->ld));
@@ -430,7 +433,9 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
 }
 
 // strips + the pass over P of one round, on the handle's stream, from `plan`
-int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan)
+// `between`, if given, is enqueued between the strips and the pass (overlapped runs: k_tick_next)
+template <typename F>
+int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan, bool compact, F between)
 {
     const int vec = 16 / (int)h->esize();
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
@@ -438,10 +443,14 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     int rc = NUSLAM_OK;
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       h->tk_KU, h->tk_RU, h->tk_SU)));
     else
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, h->B), dim3(512),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R)));
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       h->tk_KU, h->tk_RU, h->tk_SU)));
+    if (rc) return rc;
+    rc = between();
     if (rc) return rc;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
@@ -465,9 +474,9 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         View v = h->view();
         int rc = NUSLAM_OK;
         DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
-                                   (const T*)h->P(), h->tk_plan, (const TickHandoff*)nullptr, (int*)nullptr)));
+                                   (const T*)h->P(), h->tk_plan, (const TickHandoff*)nullptr, (int*)nullptr, (int*)nullptr)));
         if (rc) return rc;
-        rc = launch_strips_and_pass(h, v, o, h->tk_plan);
+        rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, [] { return (int)NUSLAM_OK; });
         if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
@@ -547,34 +556,38 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
 }
 
 // nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
-// tick's markers while it enqueues this one.  Two streams:
-//   handle's stream   predict(t) -> [chain(t) done] -> strips(t) -> pass(t)            (touches P and the state vector)
-//   chain stream      chain(t) -> [predict(t) done] -> next(t) -> chain(t+1) -> ...    (touches a 35 x 35 block)
-// chain(t+1) starts from the hand-off k_tick_next(t) forms out of plan(t) and the covariance pass(t) READS, so it runs
-// while strips(t) / pass(t) / predict(t+1) run.  Same arithmetic, same bits as the one-stream order
-// (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
+// tick's markers while it enqueues this one.  Two free-running streams, no event between them inside the loop (a
+// cross-stream hipEvent cost 10-20 us per use here); the two hand-offs per tick are counters in device memory
+// (tick_signal / k_tick_wait):
+//   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> next(t) -> pass(t)        (P, state vector)
+//   chain stream      [next(t-1)] chain(t) -> [next(t)] chain(t+1) -> ...                     (a 35 x 35 block)
+// prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read; strips(t)
+// also drops the gain / prior-row strips at that set into compact arrays; next(t) replays the round on the block and
+// applies predict(t+1): chain(t+1) starts from that -- while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic,
+// same bits as the one-stream order (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
 int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    const size_t B = (size_t)h->B;
     if (!h->stream2) {
-        // its own hardware queue, served first: a chain is one workgroup per filter and must not queue behind the
-        // pass's 256 (two plain streams of one process can share a hardware queue, which would serialise the two)
+        // its own hardware queue, served first: a chain is one workgroup per filter
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
-        HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * (size_t)h->B * kTickJ));
-        HIPCHK(hipMalloc(&h->tk_hand, sizeof(TickHandoff) * (size_t)h->B));
-        HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * (size_t)h->B));
-        HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * (size_t)h->B * kNextNW * kNextNW));
+        HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * B * kTickJ));
+        HIPCHK(hipMalloc(&h->tk_hand, sizeof(TickHandoff) * B));
+        HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * B));
+        HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * B * kTickNU * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_posmap, sizeof(int) * B * h->ld));
+        HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * B * kTickJ * 2 * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * B * kTickJ * 5 * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_SU, sizeof(double) * B * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 4));
+        HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 4, h->stream));
+        HIPCHK(hipEventCreateWithFlags(&h->ov_start, hipEventDisableTiming));
+        h->seq_chain = h->seq_next = 0;
     }
-    const int n = t_end - t_begin;
-    while ((int)h->ov_events.size() < 4 * n) {            // per tick: predict, chain, next, pass
-        hipEvent_t e = nullptr;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));   // device-scope ordering only: no L2 write-back to the host per event
-        h->ov_events.push_back(e);
-    }
-    auto ev = [&](int t, int which) { return h->ov_events[(size_t)4 * (t - t_begin) + which]; };
-    enum { E_PRED = 0, E_CHAIN = 1, E_NEXT = 2, E_PASS = 3 };
+    HIPCHK(hipMemsetAsync(h->tk_posmap, 0xff, sizeof(int) * B * h->ld, h->stream));      // every index: not in the next tick's set
     auto obs_of = [&](int t) {
         ObsArg o;
         o.a = h->tr_mx; o.b = h->tr_my; o.ids = h->tr_ids;
@@ -590,53 +603,53 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         tw.dth0 = tw.dx0 = 0.0;
         return tw;
     };
-    // the chain stream starts behind everything already enqueued on the handle's stream
-    HIPCHK(hipEventRecord(ev(t_begin, E_PASS), h->stream));
-    HIPCHK(hipStreamWaitEvent(h->stream2, ev(t_begin, E_PASS), 0));
+    int* cnt_chain = h->tk_sync + 0;
+    int* cnt_next = h->tk_sync + 1;
+    int* timeouts = h->tk_sync + 2;
+    int rc = NUSLAM_OK;
     for (int t = t_begin; t < t_end; ++t) {
         TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
-        // ---- handle's stream: predict(t); it overwrites the state buffer next(t-1) reads
-        if (t > t_begin) HIPCHK(hipStreamWaitEvent(h->stream, ev(t - 1, E_NEXT), 0));
-        int rc = do_predict(h, twist_of(t));
+        const bool more = t + 1 < t_end;
+        // ---- handle's stream: predict(t) (the control words travel with the chains after the first tick), prep(t)
+        h->predict_bookkeeping = (t == t_begin) ? 1 : 0;
+        rc = do_predict(h, twist_of(t));
+        h->predict_bookkeeping = 1;
         if (rc) return rc;
-        if (t + 1 < t_end) {
-            // the block k_tick_next(t) starts from, out of the covariance pass(t) will read (70 workgroups, 70 columns)
-            const View vg = h->view();
-            DISPATCH_T(h, rc = (launch(h, -1, k_tick_gather<T>, dim3(kNextNW, h->B), dim3(128), vg, obs_of(t), obs_of(t + 1),
-                                       (const T*)h->P(), h->tk_blk)));
-            if (rc) return rc;
-        }
-        HIPCHK(hipEventRecord(ev(t, E_PRED), h->stream));
-        // ---- chain stream: chain(t) (from P for the first tick, from the hand-off afterwards), then next(t)
         const TickObs o = obs_of(t);
         const View v = h->view();
-        if (t - 2 >= t_begin) HIPCHK(hipStreamWaitEvent(h->stream2, ev(t - 2, E_PASS), 0));   // this plan buffer was pass(t-2)'s
-        if (t == t_begin) {
-            HIPCHK(hipStreamWaitEvent(h->stream2, ev(t, E_PRED), 0));
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
-                                          total, (const T*)h->P(), plan, (const TickHandoff*)nullptr, h->tk_ctrl4)));
-        } else {
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256), 0, v, o,
-                                          total, (const T*)h->P(), plan, (const TickHandoff*)h->tk_hand, h->tk_ctrl4)));
-        }
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(ev(t, E_CHAIN), h->stream2));
-        if (t + 1 < t_end) {
-            HIPCHK(hipStreamWaitEvent(h->stream2, ev(t, E_PRED), 0));
-            const size_t lds = sizeof(double) * (2 * (size_t)kNextNW * (kNextNW + 1) + 2 * kNextNW + 8 * kNextNW) +
-                               sizeof(TickStep) * (size_t)o.J;
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(1024), lds, v, o, obs_of(t + 1),
-                                          twist_of(t + 1), (const double*)h->tk_blk, (const double*)h->state[h->sidx],
-                                          (const TickStep*)plan, (const int*)h->tk_ctrl4, h->tk_hand)));
+        if (more) {
+            DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 1, h->B), dim3(64), v, o, obs_of(t + 1),
+                                       (const T*)h->P(), h->tk_posmap, h->tk_blk)));
             if (rc) return rc;
-            HIPCHK(hipEventRecord(ev(t, E_NEXT), h->stream2));
         }
-        // ---- handle's stream: strips(t) and the pass over P
-        HIPCHK(hipStreamWaitEvent(h->stream, ev(t, E_CHAIN), 0));
-        if (getenv("NUSLAM_SERIALIZE_NEXT") && t + 1 < t_end) HIPCHK(hipStreamWaitEvent(h->stream, ev(t, E_NEXT), 0));   // experiment
-        rc = launch_strips_and_pass(h, v, o, plan);
+        // ---- chain stream: chain(t): from P for the first tick (behind predict), from next(t-1)'s hand-off afterwards
+        if (t == t_begin) {
+            HIPCHK(hipEventRecord(h->ov_start, h->stream));               // once per run
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_start, 0));
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
+                                          total, (const T*)h->P(), plan, (const TickHandoff*)nullptr, h->tk_ctrl4, cnt_chain)));
+        } else {
+            rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts);
+            if (rc) return rc;
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256), 0, v, o,
+                                          total, (const T*)h->P(), plan, (const TickHandoff*)h->tk_hand, h->tk_ctrl4, cnt_chain)));
+        }
         if (rc) return rc;
-        HIPCHK(hipEventRecord(ev(t, E_PASS), h->stream));
+        h->seq_chain += h->B;
+        // ---- handle's stream: [plan(t)] strips(t), next(t), the pass over P
+        rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts);
+        if (rc) return rc;
+        rc = launch_strips_and_pass(h, v, o, plan, more, [&]() -> int {
+            if (!more) return NUSLAM_OK;
+            int r2 = NUSLAM_OK;
+            DISPATCH_T(h, r2 = (launch(h, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(256), v, obs_of(t + 1), twist_of(t + 1),
+                                       o.J, (const double*)h->tk_blk, (const double*)h->tk_KU, (const double*)h->tk_RU,
+                                       (const double*)h->tk_SU, (const TickStep*)plan, (const int*)h->tk_ctrl4, h->tk_hand,
+                                       cnt_next)));
+            h->seq_next += h->B;
+            return r2;
+        });
+        if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
         h->pidx ^= 1;
@@ -652,7 +665,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -660,6 +673,7 @@ void free_batch(nuslam_batch* h)
         for (auto& pr : h->pending[k]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->ov_events) (void)hipEventDestroy(e);
+    if (h->ov_start) (void)hipEventDestroy(h->ov_start);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
