@@ -410,12 +410,19 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 
 // behind predict(t) on the handle's stream: the position map of U' (posmap[i] = first position of state index i in U',
 // else -1; the entries set for the previous tick's map -- U_t -- are cleared first) and the block P(U'[p], U'[q]).
+// One more workgroup (blockIdx.x == NU + 1, filter 0) waits for the chain's plan of THIS tick, so that the strips can be
+// enqueued right behind this kernel without a launch of their own for the wait.
 template <typename T>
 __global__ __launch_bounds__(64) void k_tick_prep(View v, TickObs ot, TickObs on, const T* __restrict__ P,
-                                                  int* __restrict__ posmap, double* __restrict__ blk)
+                                                  int* __restrict__ posmap, double* __restrict__ blk,
+                                                  const int* __restrict__ wait_cnt, int wait_target, int* __restrict__ timeouts)
 {
     constexpr int NU = kTickNU;
     const int b = blockIdx.y, q = blockIdx.x, p = threadIdx.x;
+    if (q == NU + 1) {
+        if (b == 0 && !tick_wait(wait_cnt, wait_target) && p == 0) atomicAdd(timeouts, 1);
+        return;
+    }
     auto index_of = [&](const TickObs& o, int pos) {
         if (pos < 3) return pos;
         const int st = (pos - 3) >> 1;
@@ -435,18 +442,18 @@ __global__ __launch_bounds__(64) void k_tick_prep(View v, TickObs ot, TickObs on
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg twn, int Jt, const double* __restrict__ blk,
+__global__ __launch_bounds__(512) void k_tick_next(View v, TickObs on, TwistArg twn, int Jt, const double* __restrict__ blk,
                                                    const double* __restrict__ KU, const double* __restrict__ RU,
                                                    const double* __restrict__ SU, const TickStep* __restrict__ plan,
                                                    const int* __restrict__ ctrl4, TickHandoff* __restrict__ hout,
                                                    int* __restrict__ done_cnt)
 {
-    constexpr int NU = kTickNU, NE = (NU * NU + 255) / 256;             // entries per thread
+    constexpr int NU = kTickNU, NT = 512, NE = (NU * NU + NT - 1) / NT;  // entries per thread
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const TickStep* pl = plan + (size_t)b * kTickJ;
 
-    __shared__ double KUl[kTickJ][2][NU + 1];
+    __shared__ double Ml[kTickJ][NU][8];          // M_s(U'[a], set_s[0..4]), before-flag, after-flag: formed once per row
     __shared__ double RUl[kTickJ][5][NU + 1];
     __shared__ double PS[kTickJ][12];             // Hc[10], c, skip
     __shared__ double FB[NU][NU + 1];
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg 
         U[4 + 2 * tid] = c + 1;
     }
     if (tid < 3) U[tid] = tid;
-    for (int e = tid; e < kTickJ * 12; e += 256) {
+    for (int e = tid; e < kTickJ * 12; e += NT) {
         const int st = e / 12, f = e % 12;
         const TickStep* ps = pl + (st < Jt ? st : 0);
         PS[st][f] = f < 10 ? ps->Hc[f] : (f == 10 ? (double)ps->c : (double)(st < Jt ? ps->skip : 1));
@@ -475,11 +482,24 @@ __global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg 
     }
     __syncthreads();
     // the strips at U' (compact, written by k_tick_panels through the position map) and the state there
-    for (int e = tid; e < kTickJ * 2 * NU; e += 256) {
-        const int st = e / (2 * NU), r = (e / NU) % 2, p = e % NU;
-        KUl[st][r][p] = KU[(((size_t)b * kTickJ + st) * 2 + r) * NU + canon[p]];
+    for (int e = tid; e < kTickJ * NU; e += NT) {
+        const int st = e / NU, p = e % NU;
+        const double* ps = PS[st];
+        const int i = U[p], c = (int)ps[10];
+        const double K0 = KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + canon[p]];
+        const double K1 = KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + canon[p]];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double kh = 0.0;                                            // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+            kh = fma(K0, ps[0 + 2 * q], kh);
+            kh = fma(K1, ps[1 + 2 * q], kh);
+            const int sidx = q < 3 ? q : c + (q - 3);
+            Ml[st][p][q] = (i == sidx ? 1.0 : 0.0) - kh;
+        }
+        Ml[st][p][5] = (i > 2 && i < c) ? 1.0 : 0.0;
+        Ml[st][p][6] = (i > c + 1) ? 1.0 : 0.0;
     }
-    for (int e = tid; e < kTickJ * 5 * NU; e += 256) {
+    for (int e = tid; e < kTickJ * 5 * NU; e += NT) {
         const int st = e / (5 * NU), q = (e / NU) % 5, p = e % NU;
         RUl[st][q][p] = RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + canon[p]];
     }
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg 
     double E[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
-        const int e = tid + 256 * k;
+        const int e = tid + NT * k;
         ea[k] = e < NU * NU ? e / NU : -1;
         eb[k] = e < NU * NU ? e % NU : 0;
         E[k] = e < NU * NU ? blk[(size_t)b * NU * NU + e] : 0.0;
@@ -498,24 +518,13 @@ __global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg 
     for (int st = 0; st < Jt; ++st) {
         const double* ps = PS[st];
         if (ps[11] != 0.0) continue;                                    // (a skipped marker moves nothing in P)
-        const int c = (int)ps[10];
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             if (ea[k] < 0) continue;
-            const int i = U[ea[k]];
-            const double K0 = KUl[st][0][ea[k]], K1 = KUl[st][1][ea[k]];
             double m[5], r[5];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                double kh = 0.0;                                        // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
-                kh = fma(K0, ps[0 + 2 * q], kh);
-                kh = fma(K1, ps[1 + 2 * q], kh);
-                const int sidx = q < 3 ? q : c + (q - 3);
-                m[q] = (i == sidx ? 1.0 : 0.0) - kh;
-                r[q] = RUl[st][q][eb[k]];
-            }
-            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
-            E[k] = p1_entry<T>(m, r, E[k], bef, aft);
+            for (int q = 0; q < 5; ++q) { m[q] = Ml[st][ea[k]][q]; r[q] = RUl[st][q][eb[k]]; }
+            E[k] = p1_entry<T>(m, r, E[k], Ml[st][ea[k]][5], Ml[st][ea[k]][6]);
         }
     }
 #pragma unroll
@@ -570,7 +579,7 @@ __global__ __launch_bounds__(256) void k_tick_next(View v, TickObs on, TwistArg 
         const int* c4 = ctrl4 + 4 * b;
         ho->seen = c4[0]; ho->cached = c4[0]; ho->brk = 0; ho->status = c4[3];     // slam.cpp:250-251 at the next tick's top
     }
-    for (int e = tid; e < NU * NU; e += 256) {
+    for (int e = tid; e < NU * NU; e += NT) {
         const int p = e / NU, q = e % NU;
         if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
         double val = FB[p][q];

@@ -617,11 +617,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         if (rc) return rc;
         const TickObs o = obs_of(t);
         const View v = h->view();
-        if (more) {
-            DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 1, h->B), dim3(64), v, o, obs_of(t + 1),
-                                       (const T*)h->P(), h->tk_posmap, h->tk_blk)));
-            if (rc) return rc;
-        }
+
         // ---- chain stream: chain(t): from P for the first tick (behind predict), from next(t-1)'s hand-off afterwards
         if (t == t_begin) {
             HIPCHK(hipEventRecord(h->ov_start, h->stream));               // once per run
@@ -636,13 +632,17 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         }
         if (rc) return rc;
         h->seq_chain += h->B;
-        // ---- handle's stream: [plan(t)] strips(t), next(t), the pass over P
-        rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts);
+        // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), next(t), the pass over P
+        if (more)
+            DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 2, h->B), dim3(64), v, o, obs_of(t + 1),
+                                       (const T*)h->P(), h->tk_posmap, h->tk_blk, (const int*)cnt_chain, h->seq_chain, timeouts)));
+        else
+            rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts);
         if (rc) return rc;
         rc = launch_strips_and_pass(h, v, o, plan, more, [&]() -> int {
             if (!more) return NUSLAM_OK;
             int r2 = NUSLAM_OK;
-            DISPATCH_T(h, r2 = (launch(h, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(256), v, obs_of(t + 1), twist_of(t + 1),
+            DISPATCH_T(h, r2 = (launch(h, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(512), v, obs_of(t + 1), twist_of(t + 1),
                                        o.J, (const double*)h->tk_blk, (const double*)h->tk_KU, (const double*)h->tk_RU,
                                        (const double*)h->tk_SU, (const TickStep*)plan, (const int*)h->tk_ctrl4, h->tk_hand,
                                        cnt_next)));
