@@ -74,7 +74,7 @@ def parse():
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
-    ap.add_argument("--overlap", action="store_true", help="opt-in: the chain of tick t+1 on a second stream (nuslam_batch_set_overlap)")
+    ap.add_argument("--overlap", action="store_true", help="force the chain of tick t+1 onto a second stream (nuslam_batch_set_overlap; default: on for one filter, off for batches)")
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")

@@ -179,9 +179,10 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
  * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
  * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle. */
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
-/* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable != 0 lets the serial chain of tick t+1 run on a
+/* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable > 0 lets the serial chain of tick t+1 run on a
  * second stream while the strips and the pass over P of tick t run on the handle's (the host knows the next tick's
- * markers from the resident trace).  Same bits either way; off by default (measured: no gain yet). */
+ * markers from the resident trace; the streams hand over through device counters, every wait bounded).  Same bits
+ * either way.  enable < 0 (default): on for a handle of one filter, off for batches (measured). */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */

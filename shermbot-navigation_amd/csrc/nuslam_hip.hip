@@ -91,8 +91,8 @@ struct nuslam_batch {
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
     int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
-    int overlap = 0;           // opt-in (nuslam_batch_set_overlap): bit-identical, but not faster yet -- k_tick_next is ~50 us on
-                               // its one CU and the pass leaves no CU free for the chain to start on
+    int overlap = -1;          // 1 / 0: nuslam_batch_set_overlap; -1: on for a single filter (96.6 vs 105.5 us per tick at N = 1000),
+                               // off for batches, whose pass fills every CU and only delays the chain (6.9M vs 7.2M updates/s)
     hipStream_t stream2 = nullptr;
     TickStep* tk_plan2 = nullptr; TickHandoff* tk_hand = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
     int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
@@ -1172,7 +1172,7 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
     h->id_log = nullptr;  // resident traces do not log resolved ids
     int rc = NUSLAM_OK;
     const bool known_trace = h->tr_ids != nullptr && !h->tr_presence_only;
-    if (h->overlap && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
+    if ((h->overlap < 0 ? h->B == 1 : h->overlap != 0) && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
         (h->tick_mode != 0) && (h->tr_bcast ? !h->h_ids.empty() : true)) {     // (auto: with the chains overlapped the pipeline pays for one filter too)
         rc = run_overlapped(h, t_begin, t_end, total_landmarks);
         h->id_log = saved_log;
@@ -1294,7 +1294,7 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
-    h->overlap = enable != 0;
+    h->overlap = enable < 0 ? -1 : (enable != 0);
     return NUSLAM_OK;
 }
 

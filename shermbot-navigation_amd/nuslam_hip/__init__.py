@@ -394,7 +394,7 @@ class Batch:
         _chk(lib().nuslam_batch_set_tick_mode(self._h, int(mode)), "batch_set_tick_mode")
 
     def set_overlap(self, enable=True):
-        _chk(lib().nuslam_batch_set_overlap(self._h, 1 if enable else 0), "batch_set_overlap")
+        _chk(lib().nuslam_batch_set_overlap(self._h, -1 if enable is None else (1 if enable else 0)), "batch_set_overlap")
 
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")
