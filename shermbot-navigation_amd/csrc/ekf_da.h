@@ -1,0 +1,498 @@
+// ekf_da.h -- a tick with UNKNOWN data association (slam.cpp:279-318 with associateLandmark, slam_library.cpp:188-253,
+// in front of every correction) as m small launches and ONE pass over the covariance.
+//
+// The per-correction path pays a full pass over P for every marker (k_associate + k_update, 2 len^2 w bytes each) although
+// associateLandmark itself reads only O(len) numbers of P: for every candidate k the 5 x 5 block P(set_k, set_k),
+// set_k = {0, 1, 2, c_k, c_k + 1}, i.e.
+//
+//     TR[q][j] = P(q, j)   rows 0..2            TC[q][i] = P(i, q)   columns 0..2
+//     TD[e][k] = P(c_k + (e & 1), c_k + (e >> 1))   the 2 x 2 diagonal blocks
+//
+// and those obey the sweep formula of ekf_update.h restricted to themselves:  P_s(i,j) = sum_k M_s(i,k) P_{s-1}(k,j)
+// needs, besides the entry, the gain row K_s(i,:) and the five prior entries R_s(:, j) = P_{s-1}(set_s, j) -- the strips
+// the tick pipeline (ekf_tick.h) forms anyway.  With known ids all strips of a tick come out of one launch (k_tick_panels);
+// here the landmark of correction s is known only after associating against the result of correction s-1, so the strips
+// are formed one correction per launch:
+//
+//   k_da_begin     TR / TC / TD / state / control words out of the covariance after predict; candidates of marker 0.
+//   k_da_step(s)   every workgroup: reduce the candidates' keys -> id (decode_association + the caller's chain); H, S,
+//                  S^-1, z_hat (redundantly, from tracked entries);  rows c, c+1 and columns c, c+1 of P_{s-1} = the tick's
+//                  starting covariance (one gather) replayed through corrections 0..s-1 from their stored strips;
+//                  R_s (5 x len), K_s (len x 2), the state;  TR / TC / TD after the correction;  the candidates of marker
+//                  s + 1 against exactly that.  One thread per (state index, role), 60 indices per workgroup.
+//   k_tick_apply   the pass over P with all strips of the round (ekf_tick.h), unchanged.
+//
+// Every entry goes through the operations k_associate / k_update perform on it, in the same order (tests/test_gpu_da.py
+// compares bit for bit), so the decisions -- match, new landmark, gray zone -- are the per-correction path's.
+#pragma once
+
+namespace nuslam {
+
+constexpr int kDaSlots = 64;     // index slots of a workgroup: slots 0..2 = the pose indices (carried by EVERY workgroup,
+constexpr int kDaOwn = 60;       // stored by workgroup 0), slots 3..62 = 60 own indices = 30 landmarks, slot 63 idle
+constexpr int kDaLm = kDaOwn / 2;
+
+struct DaBuf {
+    double* TR[2];   // [B][3][ld]
+    double* TC[2];   // [B][3][ld]
+    double* TD[2];   // [B][4][n]
+    double* DS[2];   // [B][ld]       state
+    int* DC[2];      // [B][C_WORDS]  control words
+    double* Z;       // [B][2][kTickJ] the round's markers in polar form (slam.cpp:286)
+    int* keyp;       // [B][kTickJ][nwg] association key of marker s as seen by workgroup w (min over its candidates)
+    int nwg;
+};
+
+// associateLandmark's test of one candidate (slam_library.cpp:209-246) from pb[q][q2] = P(set[q2], set[q]):
+// 0 = match, 1 = gray zone, 2 = psi singular, -1 = neither
+__device__ inline int assoc_code(const double pb[5][5], const double R[4], double th, double x, double y, double lx,
+                                 double ly, double r, double phi)
+{
+    const double min_threshold = 0.01;   // :193
+    const double max_threshold = 60;     // :194
+    double Hc[10], psi[4], psi_inv[4], zr, zb;
+    jacobian_compact(x, y, lx, ly, Hc);                    // :212
+    innovation_cov_block(pb, Hc, R, psi);                  // :215
+    measurement(th, x, y, lx, ly, zr, zb);                 // :218
+    const double dz0 = r - zr, dz1 = phi - zb;             // :229 (bearing difference not wrapped)
+    if (inv2(psi, psi_inv)) return 2;                      // psi_k.i() would throw
+    double w0 = 0.0, w1 = 0.0, d = 0.0;                    // (dz^T psi^-1) dz, :231
+    w0 = fma(dz0, psi_inv[0], w0); w0 = fma(dz1, psi_inv[1], w0);
+    w1 = fma(dz0, psi_inv[2], w1); w1 = fma(dz1, psi_inv[3], w1);
+    d = fma(w0, dz0, d); d = fma(w1, dz1, d);
+    if (d < min_threshold) return 0;                                   // :238
+    if ((d > min_threshold) && (d < max_threshold)) return 1;          // :243
+    return -1;
+}
+
+__device__ inline int da_index(int wg, int l) { return l < 3 ? l : 3 + wg * kDaOwn + (l - 3); }
+
+// ------------------------------------------------------------------------------------------------ begin
+template <typename T>
+__global__ __launch_bounds__(256) void k_da_begin(View v, TickObs o, const T* __restrict__ P, DaBuf d)
+{
+    const int b = blockIdx.y, wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = v.ld, L = v.L, n = v.n;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    const double* s = v.s_in + (size_t)b * ld;
+    const int t = da_index(wg, lane);
+    const bool own = lane < 63 && (lane >= 3 || wg == 0);
+    if (wave == 0) {
+        if (own && t < L) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d.TR[0][((size_t)b * 3 + q) * ld + t] = (double)Pb[(size_t)t * ld + q];
+        }
+    } else if (wave == 1) {
+        if (own && t < ld) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d.TC[0][((size_t)b * 3 + q) * ld + t] = (double)Pb[(size_t)q * ld + t];
+            d.DS[0][(size_t)b * ld + t] = s[t];
+        }
+    } else if (wave == 2) {
+        const int k = wg * kDaLm + lane;                   // 0-based landmark
+        if (lane < kDaLm && k < n) {
+            const int c = 3 + 2 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                d.TD[0][((size_t)b * 4 + e) * n + k] = (double)Pb[(size_t)(c + (e >> 1)) * ld + c + (e & 1)];
+        }
+    } else {
+        if (wg == 0 && lane < C_WORDS) d.DC[0][b * C_WORDS + lane] = v.c_in[b * C_WORDS + lane];
+        if (wg == 0 && lane < kTickJ) {
+            double a = 0.0, bb = 0.0;
+            if (lane < o.J) {
+                a = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
+                bb = o.b ? o.b[b * o.stride + o.off + lane] : o.b0[lane];
+            }
+            double r, phi;
+            if (o.cartesian) cartesian2polar(a, bb, r, phi);
+            else { r = a; phi = bb; }
+            d.Z[((size_t)b * 2 + 0) * kTickJ + lane] = r;
+            d.Z[((size_t)b * 2 + 1) * kTickJ + lane] = phi;
+        }
+        // the candidates of marker 0, exactly k_associate
+        const int* ci = v.c_in + b * C_WORDS;
+        const int seen = ci[C_SEEN];
+        int key = kNoKey;
+        const int k1 = wg * kDaLm + lane + 1;
+        if (!(ci[C_BRK] || seen == 0 || seen >= n) && lane < kDaLm && k1 <= seen) {
+            const double a = o.a ? o.a[b * o.stride + o.off] : o.a0[0];
+            const double bb = o.b ? o.b[b * o.stride + o.off] : o.b0[0];
+            double r, phi;
+            if (o.cartesian) cartesian2polar(a, bb, r, phi);
+            else { r = a; phi = bb; }
+            const int c = 3 + 2 * (k1 - 1);
+            const int set[5] = { 0, 1, 2, c, c + 1 };
+            double pb[5][5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = (double)Pb[(size_t)set[q] * ld + set[q2]];
+            const int code = assoc_code(pb, v.R, s[0], s[1], s[2], s[c], s[c + 1], r, phi);
+            if (code >= 0) key = k1 * 4 + code;
+        }
+        key = wave_min(key);
+        if (lane == 0) d.keyp[((size_t)b * kTickJ + 0) * d.nwg + wg] = key;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ one correction
+// wave 0: ROW role, lane = slot: column t of the prior rows (R_s), of TR
+// wave 1: COLUMN role: row t of the gain (K_s), of TC, state entry t
+// wave 2: the head: H, S, S^-1, the gain rows of the pose (what k_update's wave 0 does)
+// wave 3: the replay coefficients of rows / columns c, c+1 (uniform over the workgroup), z_hat and the innovation
+template <typename T>
+__global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int last, int total_landmarks,
+                                                 const T* __restrict__ P, DaBuf d, TickStep* __restrict__ plan,
+                                                 double* __restrict__ Kbuf, double* __restrict__ Rbuf)
+{
+    const int b = blockIdx.y, wg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = v.ld, L = v.L, n = v.n;
+    const int par = st & 1;
+    const double* TRc = d.TR[par] + (size_t)b * 3 * ld;
+    double* TRn = d.TR[par ^ 1] + (size_t)b * 3 * ld;
+    const double* TCc = d.TC[par] + (size_t)b * 3 * ld;
+    double* TCn = d.TC[par ^ 1] + (size_t)b * 3 * ld;
+    const double* TDc = d.TD[par] + (size_t)b * 4 * n;
+    double* TDn = d.TD[par ^ 1] + (size_t)b * 4 * n;
+    const double* sc = d.DS[par] + (size_t)b * ld;
+    double* sn = d.DS[par ^ 1] + (size_t)b * ld;
+    const int* cc = d.DC[par] + b * C_WORDS;
+    int* cn = d.DC[par ^ 1] + b * C_WORDS;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    TickStep* pl = plan + (size_t)b * kTickJ;
+    double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
+    double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
+    const int t = da_index(wg, lane);
+    const bool own = lane < 63 && (lane >= 3 || wg == 0);
+
+    __shared__ double hd[20];                 // Hc[10], Sinv[4], lx, ly, dz0, dz1
+    __shared__ int hi[2];                     // no correction (skip / singular), status after
+    __shared__ double Mpose[3][6];            // M_s(q, set_s), q = 0..2
+    __shared__ double hist[kTickJ][12];       // correction t' < s: Hc[10], c, skip
+    __shared__ double mcL[kTickJ][2][8];      // M_t'(c + e, set_t'), before, after
+    __shared__ double rcL[kTickJ][2][6];      // R_t'(:, c + e)
+    __shared__ double rcolL[kDaSlots][5];     // R_s(:, t) of the workgroup's columns
+    __shared__ double mrowL[kDaSlots][8];     // M_s(t, set_s), before, after of its rows
+    __shared__ double nTR[kDaSlots][3], nTC[kDaSlots][3], nS[kDaSlots], nTD[kDaLm][4];
+
+    // ---- loads that depend on kernel arguments only: tracked entries and this thread's strips of corrections 0..s-1
+    const int tr_ = t < L ? t : 0, tc_ = t < ld ? t : 0;
+    double e3[3] = { 0.0, 0.0, 0.0 }, sv = 0.0;
+    double strip[kTickJ][5];                                            // wave 0: R_t'(:, t); wave 1: [t'][0..1] = K_t'(t, :)
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) e3[q] = TRc[(size_t)q * ld + tr_];
+#pragma unroll
+        for (int tp = 0; tp < kTickJ; ++tp) {
+            const int tq = tp < st ? tp : 0;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) strip[tp][q] = Rb[(size_t)(tq * 5 + q) * ld + tr_];
+        }
+    } else if (wave == 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) e3[q] = TCc[(size_t)q * ld + tc_];
+        sv = sc[tc_];
+#pragma unroll
+        for (int tp = 0; tp < kTickJ; ++tp) {
+            const int tq = tp < st ? tp : 0;
+            strip[tp][0] = Kb[(size_t)(tq * 2 + 0) * ld + tc_];
+            strip[tp][1] = Kb[(size_t)(tq * 2 + 1) * ld + tc_];
+        }
+    }
+
+    // ---- the decision, by every wave: associateLandmark's verdict from the candidates' keys, then slam.cpp:295-316
+    int key = kNoKey;
+    for (int i = lane; i < d.nwg; i += 64) {
+        const int kk = d.keyp[((size_t)b * kTickJ + st) * d.nwg + i];
+        key = kk < key ? kk : key;
+    }
+    key = wave_min(key);
+    const int seen = cc[C_SEEN], cached = cc[C_SEEN_CACHED], brk = cc[C_BRK], status0 = cc[C_STATUS];
+    int id_raw, seen_now, status_now;
+    {
+        const Assoc a = decode_association(n, seen, brk, status0, key);
+        id_raw = a.id; seen_now = a.new_seen; status_now = a.new_status;
+        // a marker slot without a marker (presence word < 0): associateLandmark is not called for it (slam.cpp:279)
+        if (o.ids != nullptr && o.ids[b * o.stride + o.off + st] < 0) { id_raw = -1; seen_now = seen; status_now = status0; }
+    }
+    const Decision dd = resolve(n, id_raw, seen_now, cached, brk, status_now, MODE_DA, total_landmarks);
+    const int c = dd.c;
+    const int setv[5] = { 0, 1, 2, c, c + 1 };
+
+    // ---- loads that depend on the landmark
+    double g0 = 0.0, g1 = 0.0;
+    if (wave == 0) {                                                    // P0(c, t), P0(c+1, t): one line per column
+        g0 = (double)Pb[(size_t)tr_ * ld + c];
+        g1 = (double)Pb[(size_t)tr_ * ld + c + 1];
+    } else if (wave == 1) {                                             // P0(t, c), P0(t, c+1): contiguous
+        g0 = (double)Pb[(size_t)c * ld + tc_];
+        g1 = (double)Pb[(size_t)(c + 1) * ld + tc_];
+    } else if (wave == 2) {
+        // lane 5 q + q2 < 25: P_{s-1}(set[q2], set[q]); lanes 32..36: th, x, y, lx, ly; lanes 40, 41: the marker
+        const int e = lane < 25 ? lane : 0;
+        const int q = e / 5, q2 = e % 5;
+        const double* src;
+        if (q2 < 3) src = TRc + (size_t)q2 * ld + setv[q];
+        else if (q < 3) src = TCc + (size_t)q * ld + setv[q2];
+        else src = TDc + (size_t)((q2 - 3) + 2 * (q - 3)) * n + (c - 3) / 2;
+        const int sl = lane - 32;
+        if (sl >= 0 && sl < 5) src = sc + setv[sl];
+        if (sl == 8) src = d.Z + ((size_t)b * 2 + 0) * kTickJ + st;
+        if (sl == 9) src = d.Z + ((size_t)b * 2 + 1) * kTickJ + st;
+        const double val = *src;
+        const double th = lane_bcast(val, 32), x = lane_bcast(val, 33), y = lane_bcast(val, 34);
+        double lx = lane_bcast(val, 35), ly = lane_bcast(val, 36);
+        const double r = lane_bcast(val, 40), phi = lane_bcast(val, 41);
+        bool skip0 = dd.skip;
+        int stt = dd.new_status;
+        double Hc[10], Si[4];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) Hc[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Si[k] = 0.0;
+        if (!skip0) {
+            if (dd.init) {                                              // initializeLandmark, slam_library.cpp:255-261
+                lx = x + r * cos(phi + th);
+                ly = y + r * sin(phi + th);
+            }
+            double pb[5][5], S[4];
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int a2 = 0; a2 < 5; ++a2) pb[a][a2] = lane_bcast(val, 5 * a + a2);
+            jacobian_compact(x, y, lx, ly, Hc);                         // :268
+            innovation_cov_block(pb, Hc, v.R, S);                       // :270
+            if (inv2(S, Si)) { skip0 = true; if (stt == 0) stt = kStatusSingular; }
+            // the gain rows of the pose: pc[a2] = P(lane, set[a2]) (shuffled by all lanes: a lane masked out returns nothing)
+            double pc[5];
+#pragma unroll
+            for (int a2 = 0; a2 < 5; ++a2) pc[a2] = __shfl(val, 5 * a2 + (lane < 3 ? lane : 0), 64);
+            if (!skip0 && lane < 3) {
+                double K[2], m[5];
+                gain_row(pc, Hc, Si, lane, setv, K, m);
+#pragma unroll
+                for (int a2 = 0; a2 < 5; ++a2) Mpose[lane][a2] = m[a2];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) hd[k] = Hc[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hd[10 + k] = Si[k];
+            hd[14] = lx; hd[15] = ly;
+            hi[0] = skip0 ? 1 : 0; hi[1] = stt;
+        }
+    } else {
+        // lanes (t', e): the coefficients of rows / columns c + e through correction t'
+        const int tp = lane >> 1, e = lane & 1;
+        if (lane < 2 * kTickJ) {
+            const bool livep = tp < st;
+            const TickStep* ps = pl + (livep ? tp : 0);
+            const int skp = livep ? ps->skip : 1, cp = ps->c;
+            double Hp[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Hp[k] = ps->Hc[k];
+            const int i = c + e;
+            const double K0 = Kb[(size_t)((livep ? tp : 0) * 2 + 0) * ld + i], K1 = Kb[(size_t)((livep ? tp : 0) * 2 + 1) * ld + i];
+            double rr[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rr[q] = Rb[(size_t)((livep ? tp : 0) * 5 + q) * ld + i];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                double kh = 0.0;                                        // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+                kh = fma(K0, Hp[0 + 2 * q], kh);
+                kh = fma(K1, Hp[1 + 2 * q], kh);
+                const int sidx = q < 3 ? q : cp + (q - 3);
+                mcL[tp][e][q] = (i == sidx ? 1.0 : 0.0) - kh;
+                rcL[tp][e][q] = rr[q];
+            }
+            mcL[tp][e][5] = (i > 2 && i < cp) ? 1.0 : 0.0;
+            mcL[tp][e][6] = (i > cp + 1) ? 1.0 : 0.0;
+            if (e == 0) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) hist[tp][k] = Hp[k];
+                hist[tp][10] = (double)cp;
+                hist[tp][11] = (double)skp;
+            }
+        }
+        // z_hat at the (possibly just initialised) landmark and the innovation, :265, :272
+        if (!dd.skip) {
+            const double th = sc[0], x = sc[1], y = sc[2];
+            const double r = d.Z[((size_t)b * 2 + 0) * kTickJ + st], phi = d.Z[((size_t)b * 2 + 1) * kTickJ + st];
+            double lx, ly;
+            if (dd.init) { lx = x + r * cos(phi + th); ly = y + r * sin(phi + th); }
+            else { lx = sc[c]; ly = sc[c + 1]; }
+            double zr, zb;
+            measurement(th, x, y, lx, ly, zr, zb);
+            if (lane == 0) { hd[16] = r - zr; hd[17] = phi - zb; }
+        }
+    }
+    __syncthreads();
+
+    const bool nocorr = hi[0] != 0;
+    const int new_status = hi[1];
+    const double lx = hd[14], ly = hd[15];
+    double Hc[10], Si[4];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) Hc[k] = hd[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Si[k] = hd[10 + k];
+    double n3[3] = { e3[0], e3[1], e3[2] };                            // TR / TC of this slot after the correction
+    double m5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, bef = 0.0, aft = 0.0;  // wave 1: M_s(t, set_s)
+
+    if (wave == 0) {
+        if (!nocorr) {
+            // rows c, c+1 of P_{s-1} at column t: the gathered entries replayed through corrections 0..s-1
+#pragma unroll
+            for (int tp = 0; tp < kTickJ; ++tp) {
+                if (tp < st && hist[tp][11] == 0.0) {
+                    g0 = p1_entry<T>(mcL[tp][0], strip[tp], g0, mcL[tp][0][5], mcL[tp][0][6]);
+                    g1 = p1_entry<T>(mcL[tp][1], strip[tp], g1, mcL[tp][1][5], mcL[tp][1][6]);
+                }
+            }
+            const double rs[5] = { e3[0], e3[1], e3[2], g0, g1 };
+            if (own && t < L) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rcolL[lane][q] = rs[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(Mpose[q], rs, e3[q], 0.0, 0.0);
+        }
+        if (own && t < L) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) TRn[(size_t)q * ld + t] = n3[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) nTR[lane][q] = n3[q];
+    } else if (wave == 1) {
+        double snew = sv;
+        if (dd.init && !dd.skip) {                                      // initializeLandmark ran (also when update() then threw)
+            if (t == c) snew = lx;
+            if (t == c + 1) snew = ly;
+        }
+        if (!nocorr) {
+#pragma unroll
+            for (int tp = 0; tp < kTickJ; ++tp) {
+                if (tp < st && hist[tp][11] == 0.0) {
+                    const int cp = (int)hist[tp][10];
+                    double mt[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        double kh = 0.0;
+                        kh = fma(strip[tp][0], hist[tp][0 + 2 * q], kh);
+                        kh = fma(strip[tp][1], hist[tp][1 + 2 * q], kh);
+                        const int sidx = q < 3 ? q : cp + (q - 3);
+                        mt[q] = (t == sidx ? 1.0 : 0.0) - kh;
+                    }
+                    const double bp = (t > 2 && t < cp) ? 1.0 : 0.0, ap = (t > cp + 1) ? 1.0 : 0.0;
+                    g0 = p1_entry<T>(mt, rcL[tp][0], g0, bp, ap);
+                    g1 = p1_entry<T>(mt, rcL[tp][1], g1, bp, ap);
+                }
+            }
+            const double pc[5] = { e3[0], e3[1], e3[2], g0, g1 };
+            double K[2];
+            gain_row(pc, Hc, Si, t, setv, K, m5);
+            bef = (t > 2 && t < c) ? 1.0 : 0.0;
+            aft = (t > c + 1) ? 1.0 : 0.0;
+            if (own && t < ld) {
+                Kb[(size_t)(st * 2 + 0) * ld + t] = K[0];
+                Kb[(size_t)(st * 2 + 1) * ld + t] = K[1];
+            }
+            double acc = 0.0;                                           // state += K (z - z_hat), heading re-normalised (:275-276)
+            acc = fma(K[0], hd[16], acc);
+            acc = fma(K[1], hd[17], acc);
+            snew = snew + acc;
+            if (t == 0) snew = normalize_angle(snew);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) mrowL[lane][q] = m5[q];
+            mrowL[lane][5] = bef; mrowL[lane][6] = aft;
+        }
+        if (own && t < ld) {
+            sn[t] = snew;
+            if (last) v.s_out[(size_t)b * ld + t] = snew;
+        }
+        nS[lane] = snew;
+    } else if (wave == 3 && wg == 0 && lane == 0) {
+        // the correction's record for the pass over P, the control words, the id log
+        TickStep* ps = pl + st;
+        ps->skip = nocorr ? 1 : 0; ps->init = (dd.init && !dd.skip) ? 1 : 0; ps->c = c; ps->id = dd.id;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) ps->Hc[k] = Hc[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ps->Sinv[k] = Si[k];
+        ps->dz[0] = hd[16]; ps->dz[1] = hd[17]; ps->lxy[0] = lx; ps->lxy[1] = ly;
+        cn[C_SEEN] = dd.new_seen; cn[C_SEEN_CACHED] = cached; cn[C_BRK] = dd.new_brk; cn[C_STATUS] = new_status;
+        if (last) {
+            int* co = v.c_out + b * C_WORDS;
+            co[C_SEEN] = dd.new_seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = dd.new_brk; co[C_STATUS] = new_status;
+        }
+        if (v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = dd.id;
+    }
+    __syncthreads();
+
+    // ---- columns 0..2 at this row (needs R_s(:, q) = the row role's strips of slots 0..2), the diagonal blocks
+    if (wave == 1) {
+        if (!nocorr) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
+        }
+        if (own && t < ld) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) TCn[(size_t)q * ld + t] = n3[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) nTC[lane][q] = n3[q];
+    } else if (wave == 0 || wave == 2) {
+        // entry e of landmark lm: P(c_lm + (e & 1), c_lm + (e >> 1))
+        const int idx = (wave == 0 ? 0 : 64) + lane;
+        const int lm = idx >> 2, e = idx & 3;
+        const int k = wg * kDaLm + lm;
+        if (lm < kDaLm) {
+            double val = 0.0;
+            if (k < n) {
+                val = TDc[(size_t)e * n + k];
+                const int si = 3 + 2 * lm + (e & 1), sj = 3 + 2 * lm + (e >> 1);
+                if (!nocorr) val = p1_entry<T>(mrowL[si], rcolL[sj], val, mrowL[si][5], mrowL[si][6]);
+                TDn[(size_t)e * n + k] = val;
+            }
+            nTD[lm][e] = val;
+        }
+    }
+    if (st + 1 >= o.J) return;                                          // the round's last correction: nothing to associate
+    __syncthreads();
+
+    // ---- the candidates of marker s+1 against the state and covariance this correction leaves (k_associate)
+    if (wave == 0) {
+        const int seen1 = dd.new_seen;
+        int key1 = kNoKey;
+        const int k1 = wg * kDaLm + lane + 1;
+        if (!(dd.new_brk || seen1 == 0 || seen1 >= n) && lane < kDaLm && k1 <= seen1) {
+            const double r = d.Z[((size_t)b * 2 + 0) * kTickJ + st + 1], phi = d.Z[((size_t)b * 2 + 1) * kTickJ + st + 1];
+            const int s0 = 3 + 2 * lane;                                // slot of c_k
+            double pb[5][5];                                            // pb[q][q2] = P(set[q2], set[q])
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int q2 = 0; q2 < 5; ++q2) {
+                    double val;
+                    if (q2 < 3) val = nTR[q < 3 ? q : s0 + (q - 3)][q2];                   // row q2 at column set[q]
+                    else if (q < 3) val = nTC[s0 + (q2 - 3)][q];                          // column q at row set[q2]
+                    else val = nTD[lane][(q2 - 3) + 2 * (q - 3)];
+                    pb[q][q2] = val;
+                }
+            const int code = assoc_code(pb, v.R, nS[0], nS[1], nS[2], nS[s0], nS[s0 + 1], r, phi);
+            if (code >= 0) key1 = k1 * 4 + code;
+        }
+        key1 = wave_min(key1);
+        if (lane == 0) d.keyp[((size_t)b * kTickJ + st + 1) * d.nwg + wg] = key1;
+    }
+}
+
+} // namespace nuslam

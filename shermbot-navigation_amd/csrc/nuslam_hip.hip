@@ -88,6 +88,9 @@ struct nuslam_batch {
     int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
+    // unknown association (ekf_da.h): tracked rows / columns / diagonal blocks of P, one launch per correction
+    DaBuf da = {};
+    void* da_mem = nullptr;
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
     int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
@@ -432,14 +435,29 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
     return o;
 }
 
+// The pass over P of one round from the plan and the strips in tk_K / tk_R
+int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan)
+{
+    const int vec = 16 / (int)h->esize();
+    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
+    const int waves = sweep_waves(h, vec, strips);
+    int rc = NUSLAM_OK;
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
+    const size_t lds = sizeof(double) * ((size_t)J * 2 * 64 * vec + (size_t)waves * J * 5 * kSweepCW);
+    if (waves == 8)
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, J, plan,
+                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
+    else
+        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, J, plan,
+                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
+    return rc;
+}
+
 // strips + the pass over P of one round, on the handle's stream, from `plan`
 // `between`, if given, is enqueued between the strips and the pass (overlapped runs: k_tick_next)
 template <typename F>
 int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan, bool compact, F between)
 {
-    const int vec = 16 / (int)h->esize();
-    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    const int waves = sweep_waves(h, vec, strips);
     int rc = NUSLAM_OK;
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
@@ -452,15 +470,57 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     if (rc) return rc;
     rc = between();
     if (rc) return rc;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
-    const size_t lds = sizeof(double) * ((size_t)o.J * 2 * 64 * vec + (size_t)waves * o.J * 5 * kSweepCW);
-    if (waves == 8)
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, o.J, plan,
-                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
-    else
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, o.J, plan,
-                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
-    return rc;
+    return launch_pass(h, v, o.J, plan);
+}
+
+int ensure_da_buffers(nuslam_batch* h)
+{
+    if (h->da_mem) return NUSLAM_OK;
+    const size_t B = h->B, ld = h->ld, n = h->n;
+    const int nwg = (h->ld - 3 + kDaOwn - 1) / kDaOwn > 0 ? (h->ld - 3 + kDaOwn - 1) / kDaOwn : 1;
+    // one allocation: 2 x (TR, TC) [B][3][ld], 2 x TD [B][4][n], 2 x DS [B][ld], Z [B][2][kTickJ]; then the int arrays
+    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ;
+    const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg;
+    HIPCHK(hipMalloc(&h->da_mem, nd * sizeof(double) + ni * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->da_mem, 0, nd * sizeof(double) + ni * sizeof(int), h->stream));
+    double* p = (double*)h->da_mem;
+    for (int k = 0; k < 2; ++k) { h->da.TR[k] = p; p += B * 3 * ld; }
+    for (int k = 0; k < 2; ++k) { h->da.TC[k] = p; p += B * 3 * ld; }
+    for (int k = 0; k < 2; ++k) { h->da.TD[k] = p; p += B * 4 * n; }
+    for (int k = 0; k < 2; ++k) { h->da.DS[k] = p; p += B * ld; }
+    h->da.Z = p; p += B * 2 * kTickJ;
+    int* q = (int*)p;
+    for (int k = 0; k < 2; ++k) { h->da.DC[k] = q; q += B * C_WORDS; }
+    h->da.keyp = q;
+    h->da.nwg = nwg;
+    return NUSLAM_OK;
+}
+
+// The markers of an unknown-association tick in rounds of up to kTickJ (ekf_da.h): k_da_begin, one k_da_step per marker,
+// then the one pass over P.
+int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const double* host_mx, const double* host_my)
+{
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    { int erc = ensure_da_buffers(h); if (erc) return erc; }
+    for (int i0 = 0; i0 < m; i0 += kTickJ) {
+        const TickObs o = make_tick_obs(h, base, i0, m, nullptr, host_mx, host_my);
+        View v = h->view();
+        int rc = NUSLAM_OK;
+        const dim3 grid(h->da.nwg, h->B), block(256);
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_BEGIN, k_da_begin<T>, grid, block, v, o, (const T*)h->P(), h->da)));
+        if (rc) return rc;
+        for (int st = 0; st < o.J; ++st) {
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_STEP, k_da_step<T>, grid, block, v, o, st, st + 1 == o.J ? 1 : 0, total,
+                                       (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R)));
+            if (rc) return rc;
+        }
+        rc = launch_pass(h, v, o.J, h->tk_plan);
+        if (rc) return rc;
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+        h->pidx ^= 1;
+    }
+    return NUSLAM_OK;
 }
 
 // The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
@@ -499,6 +559,12 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         rc = do_tick_rounds(h, base, m, total, host_ids, host_mx, host_my);
         if (rc) return rc;
         h->host_seen_valid = false;                 // (the mirror only serves the per-correction path's pairing)
+        return NUSLAM_OK;
+    }
+    if (!known && tick_pipeline_pays(h, m) && !h->deferred && m > 0 && h->n >= 1) {
+        rc = do_da_rounds(h, base, m, total, host_mx, host_my);
+        if (rc) return rc;
+        h->host_seen_valid = false;
         return NUSLAM_OK;
     }
     auto id_of = [&](int b, int i) { return host_ids ? host_ids[i] : pf_ids[(size_t)b * pf_stride + i]; };
@@ -665,7 +731,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
