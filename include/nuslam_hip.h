@@ -39,6 +39,8 @@ typedef enum {
     NUSLAM_E_NODEV = 5,     /* no HIP device available */
     NUSLAM_E_NOMEM = 6,
     NUSLAM_E_COMM = 8,      /* RCCL could not be loaded or a collective failed; nuslam_last_hip_error() has the text */
+    NUSLAM_E_SYNC = 9,      /* a bounded device-side wait between workgroups / streams expired (resident unknown-association
+                               round, overlapped run): latched like the others; the results of that run are invalid */
     NUSLAM_E_CAPACITY = 7   /* a fixed-size device table is too small for this input (nuslam_batch_simulate with lidar:
                                a scan left more clusters than the per-scan table of 64 holds) */
 } nuslam_status;
@@ -177,7 +179,11 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
  * entries carried through the corrections: H, S^-1, K, the innovation), then the O(len) gain / prior-row strips,
  * then ONE pass over the covariance that carries every tile through all corrections: 2 len^2 w bytes per tick.
  * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
- * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle. */
+ * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle.
+ * Ticks with UNKNOWN association follow the same switch: mode 1 = tracked rows / columns / diagonal blocks of the
+ * covariance, one O(len) step per marker and one pass over the covariance per tick (csrc/ekf_da.h) -- as ONE resident
+ * launch per round while the handle's workgroups fit the chip, else one launch per marker; mode 2 = always one launch
+ * per marker; mode 0 = associate + one pass per marker.  Identical bits in every mode. */
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
 /* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable > 0 lets the serial chain of tick t+1 run on a
  * second stream while the strips and the pass over P of tick t run on the handle's (the host knows the next tick's

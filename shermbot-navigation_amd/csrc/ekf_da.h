@@ -495,4 +495,451 @@ __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ a whole round, resident
+// The same corrections as k_da_begin + J x k_da_step, as ONE launch whose workgroups stay resident and meet at a counter
+// in global memory between corrections (grid of nwg x B workgroups, all of which must be on the chip at once: the host
+// takes this path only while nwg * B fits the CUs, see do_da_rounds).  What a kernel boundary cost per correction --
+// dispatch, the re-load of every thread's tracked entries and of its strips of corrections 0..s-1 -- stays in registers
+// and LDS; what other workgroups need (the tracked entries of whichever landmark is associated next, the strips at its
+// two indices, the candidates' keys) still travels through global memory -- every such store and every such load at
+// agent scope (`sc1`: write-through, L1-bypassing), every storing wave drained (vmcnt(0)) in front of the workgroup
+// barrier behind which ONE lane bumps the counter, the counter polled with an sc1 load, a workgroup barrier between the
+// poll and the loads: the fence-free hand-off of MI355X_MICROARCH.md "Valid forms" (first table row).  An agent-scope
+// release + acquire pair per correction instead (L2 write-back + L1 invalidate, ~1.7 us each) made the resident kernel
+// no faster than one launch per marker.  Every wait is bounded; an expired one latches NUSLAM_E_SYNC in the filter's
+// status word instead of hanging the device.
+constexpr int kStatusSync = 9;      // NUSLAM_E_SYNC
+
+__device__ inline void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_agent(const double* p)
+{
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int ld_agent(const int* p)
+{
+    return __hip_atomic_load(const_cast<int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every thread of the workgroup: arrive at the filter's counter, wait until it has reached `target`
+__device__ inline bool round_meet(int* cnt, int target)
+{
+    __shared__ int ok_sh;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (int it = 0; it < (1 << 20); ++it) {
+            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        ok_sh = ok;
+    }
+    __syncthreads();
+    return ok_sh != 0;
+}
+constexpr int kDaRoundLds = (kTickJ * 5 + kTickJ * 2) * kDaSlots * (int)sizeof(double);
+
+#ifdef NUSLAM_DA_CLOCK
+__device__ long long g_da_clock[4][16];       // debug builds (make daclock): per wave of workgroup 0, 100 MHz ticks per phase
+#define DCK(k) do { const long long n__ = (long long)wall_clock64(); dck[k] += n__ - dct; dct = n__; } while (0)
+#else
+#define DCK(k) do { } while (0)
+#endif
+template <typename T>
+__global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_landmarks, const T* __restrict__ P, DaBuf d,
+                                                  TickStep* __restrict__ plan, double* __restrict__ Kbuf,
+                                                  double* __restrict__ Rbuf, int* __restrict__ bar, int bar_base)
+{
+    const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = v.ld, L = v.L, n = v.n, J = o.J;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    TickStep* pl = plan + (size_t)b * kTickJ;
+    double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
+    double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
+    int* cnt = bar + b;
+    const int t = da_index(wg, lane);
+    const bool own = lane < 63 && (lane >= 3 || wg == 0);
+    const int tr_ = t < L ? t : 0, tc_ = t < ld ? t : 0;
+
+    extern __shared__ double da_lds[];
+    double* Rl = da_lds;                                   // [kTickJ][5][64]  R_t'(:, t) of this workgroup's columns
+    double* Kl = da_lds + kTickJ * 5 * kDaSlots;           // [kTickJ][2][64]  K_t'(t, :) of its rows
+    __shared__ double hd[20];
+    __shared__ int hi[2];
+    __shared__ double Mpose[3][6];
+    __shared__ double hist[kTickJ][12];
+    __shared__ double mcL[kTickJ][2][8];
+    __shared__ double rcL[kTickJ][2][6];
+    __shared__ double rcolL[kDaSlots][5];
+    __shared__ double mrowL[kDaSlots][8];
+    __shared__ double nTR[kDaSlots][3], nTC[kDaSlots][3], nS[kDaSlots], nTD[kDaLm][4];
+    __shared__ double Zl[2][kTickJ];
+
+    // ---- prologue (k_da_begin): the tracked entries out of the covariance after predict
+    double e3[3] = { 0.0, 0.0, 0.0 }, sv = 0.0;            // wave 0: TR[.][t]; wave 1: TC[.][t] and the state entry
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            e3[q] = (double)Pb[(size_t)tr_ * ld + q];
+            nTR[lane][q] = e3[q];
+            if (own && t < L) st_agent(&d.TR[0][((size_t)b * 3 + q) * ld + t], e3[q]);
+        }
+    } else if (wave == 1) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            e3[q] = (double)Pb[(size_t)q * ld + tc_];
+            nTC[lane][q] = e3[q];
+            if (own && t < ld) st_agent(&d.TC[0][((size_t)b * 3 + q) * ld + t], e3[q]);
+        }
+        sv = v.s_in[(size_t)b * ld + tc_];
+        nS[lane] = sv;
+        if (own && t < ld) st_agent(&d.DS[0][(size_t)b * ld + t], sv);
+    } else if (wave == 2) {
+        const int k = wg * kDaLm + lane;
+        if (lane < kDaLm) {
+            const int c0 = 3 + 2 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double val = 0.0;
+                if (k < n) {
+                    val = (double)Pb[(size_t)(c0 + (e >> 1)) * ld + c0 + (e & 1)];
+                    st_agent(&d.TD[0][((size_t)b * 4 + e) * n + k], val);
+                }
+                nTD[lane][e] = val;
+            }
+        }
+    } else if (lane < kTickJ) {
+        double a = 0.0, bb = 0.0;
+        if (lane < J) {
+            a = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
+            bb = o.b ? o.b[b * o.stride + o.off + lane] : o.b0[lane];
+        }
+        double r, phi;
+        if (o.cartesian) cartesian2polar(a, bb, r, phi);
+        else { r = a; phi = bb; }
+        Zl[0][lane] = r;
+        Zl[1][lane] = phi;
+    }
+#ifdef NUSLAM_DA_CLOCK
+    long long dck[16] = { 0 }, dct = (long long)wall_clock64();
+#endif
+    int seen, cached, brk, status;
+    {
+        const int* ci = v.c_in + b * C_WORDS;
+        seen = ci[C_SEEN]; cached = ci[C_SEEN_CACHED]; brk = ci[C_BRK]; status = ci[C_STATUS];
+    }
+
+    for (int st = -1; st < J; ++st) {
+        if (st >= 0) {
+            const int par = st & 1;
+            const double* TRc = d.TR[par] + (size_t)b * 3 * ld;
+            double* TRn = d.TR[par ^ 1] + (size_t)b * 3 * ld;
+            const double* TCc = d.TC[par] + (size_t)b * 3 * ld;
+            double* TCn = d.TC[par ^ 1] + (size_t)b * 3 * ld;
+            const double* TDc = d.TD[par] + (size_t)b * 4 * n;
+            double* TDn = d.TD[par ^ 1] + (size_t)b * 4 * n;
+            const double* sc = d.DS[par] + (size_t)b * ld;
+            double* sn = d.DS[par ^ 1] + (size_t)b * ld;
+            const bool last = st + 1 == J;
+
+            DCK(0);
+            // ---- the decision, by every wave
+            int key = kNoKey;
+            for (int i = lane; i < nwg; i += 64) {
+                const int kk = ld_agent(&d.keyp[((size_t)b * kTickJ + st) * nwg + i]);
+                key = kk < key ? kk : key;
+            }
+            key = wave_min(key);
+            int id_raw, seen_now, status_now;
+            {
+                const Assoc a = decode_association(n, seen, brk, status, key);
+                id_raw = a.id; seen_now = a.new_seen; status_now = a.new_status;
+                if (o.ids != nullptr && o.ids[b * o.stride + o.off + st] < 0) { id_raw = -1; seen_now = seen; status_now = status; }
+            }
+            const Decision dd = resolve(n, id_raw, seen_now, cached, brk, status_now, MODE_DA, total_landmarks);
+            const int c = dd.c;
+            const int setv[5] = { 0, 1, 2, c, c + 1 };
+            DCK(1);
+
+            // ---- loads that depend on the landmark
+            double g0 = 0.0, g1 = 0.0;
+            if (wave == 0) {
+                g0 = (double)Pb[(size_t)tr_ * ld + c];
+                g1 = (double)Pb[(size_t)tr_ * ld + c + 1];
+            } else if (wave == 1) {
+                g0 = (double)Pb[(size_t)c * ld + tc_];
+                g1 = (double)Pb[(size_t)(c + 1) * ld + tc_];
+            } else if (wave == 2) {
+                const int e = lane < 25 ? lane : 0;
+                const int q = e / 5, q2 = e % 5;
+                const double* src;
+                if (q2 < 3) src = TRc + (size_t)q2 * ld + setv[q];
+                else if (q < 3) src = TCc + (size_t)q * ld + setv[q2];
+                else src = TDc + (size_t)((q2 - 3) + 2 * (q - 3)) * n + (c - 3) / 2;
+                const int sl = lane - 32;
+                if (sl >= 0 && sl < 5) src = sc + setv[sl];
+                const double val = ld_agent(src);
+                const double th = lane_bcast(val, 32), x = lane_bcast(val, 33), y = lane_bcast(val, 34);
+                double lx = lane_bcast(val, 35), ly = lane_bcast(val, 36);
+                const double r = Zl[0][st], phi = Zl[1][st];
+                bool skip0 = dd.skip;
+                int stt = dd.new_status;
+                double Hc[10], Si[4];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) Hc[k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) Si[k] = 0.0;
+                if (!skip0) {
+                    if (dd.init) {                                      // initializeLandmark, slam_library.cpp:255-261
+                        lx = x + r * cos(phi + th);
+                        ly = y + r * sin(phi + th);
+                    }
+                    double pb[5][5], S[4];
+#pragma unroll
+                    for (int a = 0; a < 5; ++a)
+#pragma unroll
+                        for (int a2 = 0; a2 < 5; ++a2) pb[a][a2] = lane_bcast(val, 5 * a + a2);
+                    jacobian_compact(x, y, lx, ly, Hc);                 // :268
+                    innovation_cov_block(pb, Hc, v.R, S);               // :270
+                    if (inv2(S, Si)) { skip0 = true; if (stt == 0) stt = kStatusSingular; }
+                    double pc[5];
+#pragma unroll
+                    for (int a2 = 0; a2 < 5; ++a2) pc[a2] = __shfl(val, 5 * a2 + (lane < 3 ? lane : 0), 64);
+                    if (!skip0 && lane < 3) {
+                        double K[2], m[5];
+                        gain_row(pc, Hc, Si, lane, setv, K, m);
+#pragma unroll
+                        for (int a2 = 0; a2 < 5; ++a2) Mpose[lane][a2] = m[a2];
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) hd[k] = Hc[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hd[10 + k] = Si[k];
+                    hd[14] = lx; hd[15] = ly;
+                    hi[0] = skip0 ? 1 : 0; hi[1] = stt;
+                }
+            } else {
+                const int tp = lane >> 1, e = lane & 1;
+                if (lane < 2 * kTickJ && tp < st) {
+                    const int cp = (int)hist[tp][10];
+                    const int i = c + e;
+                    const double K0 = ld_agent(&Kb[(size_t)(tp * 2 + 0) * ld + i]), K1 = ld_agent(&Kb[(size_t)(tp * 2 + 1) * ld + i]);
+                    double rr[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) rr[q] = ld_agent(&Rb[(size_t)(tp * 5 + q) * ld + i]);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        double kh = 0.0;
+                        kh = fma(K0, hist[tp][0 + 2 * q], kh);
+                        kh = fma(K1, hist[tp][1 + 2 * q], kh);
+                        const int sidx = q < 3 ? q : cp + (q - 3);
+                        mcL[tp][e][q] = (i == sidx ? 1.0 : 0.0) - kh;
+                        rcL[tp][e][q] = rr[q];
+                    }
+                    mcL[tp][e][5] = (i > 2 && i < cp) ? 1.0 : 0.0;
+                    mcL[tp][e][6] = (i > cp + 1) ? 1.0 : 0.0;
+                }
+                if (!dd.skip) {
+                    const double th = ld_agent(&sc[0]), x = ld_agent(&sc[1]), y = ld_agent(&sc[2]);
+                    const double r = Zl[0][st], phi = Zl[1][st];
+                    double lx, ly;
+                    if (dd.init) { lx = x + r * cos(phi + th); ly = y + r * sin(phi + th); }
+                    else { lx = ld_agent(&sc[c]); ly = ld_agent(&sc[c + 1]); }
+                    double zr, zb;
+                    measurement(th, x, y, lx, ly, zr, zb);
+                    if (lane == 0) { hd[16] = r - zr; hd[17] = phi - zb; }
+                }
+            }
+            DCK(2);
+            __syncthreads();
+            DCK(3);
+
+            const bool nocorr = hi[0] != 0;
+            const int new_status = hi[1];
+            const double lx = hd[14], ly = hd[15];
+            double Hc[10], Si[4];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) Hc[k] = hd[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Si[k] = hd[10 + k];
+            double n3[3] = { e3[0], e3[1], e3[2] };
+            double m5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, bef = 0.0, aft = 0.0;
+
+            if (wave == 0) {
+                if (!nocorr) {
+                    for (int tp = 0; tp < st; ++tp) {
+                        if (hist[tp][11] == 0.0) {
+                            double r[5];
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) r[q] = Rl[(tp * 5 + q) * kDaSlots + lane];
+                            g0 = p1_entry<T>(mcL[tp][0], r, g0, mcL[tp][0][5], mcL[tp][0][6]);
+                            g1 = p1_entry<T>(mcL[tp][1], r, g1, mcL[tp][1][5], mcL[tp][1][6]);
+                        }
+                    }
+                    const double rs[5] = { e3[0], e3[1], e3[2], g0, g1 };
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        Rl[(st * 5 + q) * kDaSlots + lane] = rs[q];
+                        rcolL[lane][q] = rs[q];
+                        if (own && t < L) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rs[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(Mpose[q], rs, e3[q], 0.0, 0.0);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (own && t < L) st_agent(&TRn[(size_t)q * ld + t], n3[q]);
+                    nTR[lane][q] = n3[q];
+                    e3[q] = n3[q];
+                }
+            } else if (wave == 1) {
+                double snew = sv;
+                if (dd.init && !dd.skip) {
+                    if (t == c) snew = lx;
+                    if (t == c + 1) snew = ly;
+                }
+                if (!nocorr) {
+                    for (int tp = 0; tp < st; ++tp) {
+                        if (hist[tp][11] == 0.0) {
+                            const int cp = (int)hist[tp][10];
+                            const double K0 = Kl[(tp * 2 + 0) * kDaSlots + lane], K1 = Kl[(tp * 2 + 1) * kDaSlots + lane];
+                            double mt[5];
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) {
+                                double kh = 0.0;
+                                kh = fma(K0, hist[tp][0 + 2 * q], kh);
+                                kh = fma(K1, hist[tp][1 + 2 * q], kh);
+                                const int sidx = q < 3 ? q : cp + (q - 3);
+                                mt[q] = (t == sidx ? 1.0 : 0.0) - kh;
+                            }
+                            const double bp = (t > 2 && t < cp) ? 1.0 : 0.0, ap = (t > cp + 1) ? 1.0 : 0.0;
+                            g0 = p1_entry<T>(mt, rcL[tp][0], g0, bp, ap);
+                            g1 = p1_entry<T>(mt, rcL[tp][1], g1, bp, ap);
+                        }
+                    }
+                    const double pc[5] = { e3[0], e3[1], e3[2], g0, g1 };
+                    double K[2];
+                    gain_row(pc, Hc, Si, t, setv, K, m5);
+                    bef = (t > 2 && t < c) ? 1.0 : 0.0;
+                    aft = (t > c + 1) ? 1.0 : 0.0;
+                    Kl[(st * 2 + 0) * kDaSlots + lane] = K[0];
+                    Kl[(st * 2 + 1) * kDaSlots + lane] = K[1];
+                    if (own && t < ld) {
+                        st_agent(&Kb[(size_t)(st * 2 + 0) * ld + t], K[0]);
+                        st_agent(&Kb[(size_t)(st * 2 + 1) * ld + t], K[1]);
+                    }
+                    double acc = 0.0;
+                    acc = fma(K[0], hd[16], acc);
+                    acc = fma(K[1], hd[17], acc);
+                    snew = snew + acc;
+                    if (t == 0) snew = normalize_angle(snew);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) mrowL[lane][q] = m5[q];
+                    mrowL[lane][5] = bef; mrowL[lane][6] = aft;
+                }
+                if (own && t < ld) {
+                    st_agent(&sn[t], snew);
+                    if (last) v.s_out[(size_t)b * ld + t] = snew;
+                }
+                nS[lane] = snew;
+                sv = snew;
+            } else if (wave == 3 && lane == 0) {
+                if (wg == 0) {
+                    TickStep* ps = pl + st;
+                    ps->skip = nocorr ? 1 : 0; ps->init = (dd.init && !dd.skip) ? 1 : 0; ps->c = c; ps->id = dd.id;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) ps->Hc[k] = Hc[k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ps->Sinv[k] = Si[k];
+                    ps->dz[0] = hd[16]; ps->dz[1] = hd[17]; ps->lxy[0] = lx; ps->lxy[1] = ly;
+                    if (last) {
+                        int* co = v.c_out + b * C_WORDS;
+                        co[C_SEEN] = dd.new_seen; co[C_SEEN_CACHED] = cached; co[C_BRK] = dd.new_brk; co[C_STATUS] = new_status;
+                    }
+                    if (v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = dd.id;
+                }
+            }
+            DCK(4);
+            __syncthreads();
+            DCK(5);
+            if (wave == 3 && lane == 0) {                               // (after the barrier: wave 3's lanes were still reading hist)
+#pragma unroll
+                for (int k = 0; k < 10; ++k) hist[st][k] = Hc[k];
+                hist[st][10] = (double)c;
+                hist[st][11] = nocorr ? 1.0 : 0.0;
+            }
+
+            if (wave == 1) {
+                if (!nocorr) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (own && t < ld) st_agent(&TCn[(size_t)q * ld + t], n3[q]);
+                    nTC[lane][q] = n3[q];
+                    e3[q] = n3[q];
+                }
+            } else if (wave == 0 || wave == 2) {
+                const int idx = (wave == 0 ? 0 : 64) + lane;
+                const int lm = idx >> 2, e = idx & 3;
+                const int k = wg * kDaLm + lm;
+                if (lm < kDaLm && k < n) {
+                    double val = nTD[lm][e];
+                    const int si = 3 + 2 * lm + (e & 1), sj = 3 + 2 * lm + (e >> 1);
+                    if (!nocorr) val = p1_entry<T>(mrowL[si], rcolL[sj], val, mrowL[si][5], mrowL[si][6]);
+                    st_agent(&TDn[(size_t)e * n + k], val);
+                    nTD[lm][e] = val;
+                }
+            }
+            seen = dd.new_seen; brk = dd.new_brk; status = new_status;
+            DCK(6);
+            if (last) break;
+            __syncthreads();
+            DCK(7);
+        } else {
+            __syncthreads();
+        }
+
+        // ---- the candidates of marker st + 1 against what this correction (or the prologue) left: k_associate
+        if (wave == 0) {
+            int key1 = kNoKey;
+            const int k1 = wg * kDaLm + lane + 1;
+            if (!(brk || seen == 0 || seen >= n) && lane < kDaLm && k1 <= seen) {
+                const double r = Zl[0][st + 1], phi = Zl[1][st + 1];
+                const int s0 = 3 + 2 * lane;
+                double pb[5][5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q)
+#pragma unroll
+                    for (int q2 = 0; q2 < 5; ++q2) {
+                        double val;
+                        if (q2 < 3) val = nTR[q < 3 ? q : s0 + (q - 3)][q2];
+                        else if (q < 3) val = nTC[s0 + (q2 - 3)][q];
+                        else val = nTD[lane][(q2 - 3) + 2 * (q - 3)];
+                        pb[q][q2] = val;
+                    }
+                const int code = assoc_code(pb, v.R, nS[0], nS[1], nS[2], nS[s0], nS[s0 + 1], r, phi);
+                if (code >= 0) key1 = k1 * 4 + code;
+            }
+            key1 = wave_min(key1);
+            if (lane == 0) st_agent(&d.keyp[((size_t)b * kTickJ + st + 1) * nwg + wg], key1);
+        }
+        // ---- meet the other workgroups of this filter: everything stored above is published, everything they stored is
+        // visible behind the wait
+        DCK(8);
+        if (!round_meet(cnt, bar_base + nwg * (st + 2)) && status == 0) status = kStatusSync;
+        DCK(9);
+    }
+#ifdef NUSLAM_DA_CLOCK
+    if (lane == 0 && b == 0 && wg == 0)
+        for (int k = 0; k < 16; ++k) g_da_clock[wave][k] = dck[k];
+#endif
+}
+
 } // namespace nuslam

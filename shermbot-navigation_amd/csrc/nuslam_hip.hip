@@ -91,6 +91,8 @@ struct nuslam_batch {
     // unknown association (ekf_da.h): tracked rows / columns / diagonal blocks of P, one launch per correction
     DaBuf da = {};
     void* da_mem = nullptr;
+    int* da_bar = nullptr;     // [B] arrival counters of the resident round kernel (monotonic, never reset)
+    unsigned da_bar_seq = 0;   // their value when every round enqueued so far has passed
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
     int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
@@ -394,7 +396,7 @@ int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, 
 // smaller (N = 1000, 16 markers: 105 us per tick against 121 us for eight pair launches).
 bool tick_pipeline_pays(const nuslam_batch* h, int m)
 {
-    if (h->tick_mode >= 0) return h->tick_mode == 1;
+    if (h->tick_mode >= 0) return h->tick_mode >= 1;
     return m >= 4;                                  // (fewer markers: the fixed cost of three launches is not recovered)
 }
 
@@ -480,7 +482,7 @@ int ensure_da_buffers(nuslam_batch* h)
     const int nwg = (h->ld - 3 + kDaOwn - 1) / kDaOwn > 0 ? (h->ld - 3 + kDaOwn - 1) / kDaOwn : 1;
     // one allocation: 2 x (TR, TC) [B][3][ld], 2 x TD [B][4][n], 2 x DS [B][ld], Z [B][2][kTickJ]; then the int arrays
     const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ;
-    const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg;
+    const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg + B;
     HIPCHK(hipMalloc(&h->da_mem, nd * sizeof(double) + ni * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->da_mem, 0, nd * sizeof(double) + ni * sizeof(int), h->stream));
     double* p = (double*)h->da_mem;
@@ -491,8 +493,11 @@ int ensure_da_buffers(nuslam_batch* h)
     h->da.Z = p; p += B * 2 * kTickJ;
     int* q = (int*)p;
     for (int k = 0; k < 2; ++k) { h->da.DC[k] = q; q += B * C_WORDS; }
-    h->da.keyp = q;
+    h->da.keyp = q; q += B * kTickJ * (size_t)nwg;
+    h->da_bar = q;
     h->da.nwg = nwg;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
     return NUSLAM_OK;
 }
 
@@ -507,12 +512,21 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
         View v = h->view();
         int rc = NUSLAM_OK;
         const dim3 grid(h->da.nwg, h->B), block(256);
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_BEGIN, k_da_begin<T>, grid, block, v, o, (const T*)h->P(), h->da)));
-        if (rc) return rc;
-        for (int st = 0; st < o.J; ++st) {
-            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_STEP, k_da_step<T>, grid, block, v, o, st, st + 1 == o.J ? 1 : 0, total,
-                                       (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R)));
+        // all workgroups of the resident kernel must be on the chip together (they wait for each other): one per CU at most
+        const bool resident = h->tick_mode != 2 && (long long)h->da.nwg * h->B <= h->n_cu;
+        if (resident) {
+            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T>, grid, block, (size_t)kDaRoundLds, v, o, total,
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, h->da_bar, (int)h->da_bar_seq)));
             if (rc) return rc;
+            h->da_bar_seq += (unsigned)h->da.nwg * (unsigned)o.J;     // every workgroup arrives once per marker
+        } else {
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_BEGIN, k_da_begin<T>, grid, block, v, o, (const T*)h->P(), h->da)));
+            if (rc) return rc;
+            for (int st = 0; st < o.J; ++st) {
+                DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_STEP, k_da_step<T>, grid, block, v, o, st, st + 1 == o.J ? 1 : 0, total,
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R)));
+                if (rc) return rc;
+            }
         }
         rc = launch_pass(h, v, o.J, h->tk_plan);
         if (rc) return rc;
@@ -827,6 +841,14 @@ int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
     int st = 0, bad = -1;
     for (int b = 0; b < h->B; ++b)
         if (c[(size_t)b * C_WORDS + C_STATUS] != 0) { st = c[(size_t)b * C_WORDS + C_STATUS]; bad = b; break; }
+    if (h->tk_sync) {                              // overlapped runs: a hand-off between the two streams that never arrived
+        int expired = 0;
+        HIPCHK(hipMemcpy(&expired, h->tk_sync + 2, sizeof(int), hipMemcpyDeviceToHost));
+        if (expired) {
+            if (!st) { st = NUSLAM_E_SYNC; bad = 0; }
+            if (clear) HIPCHK(hipMemset(h->tk_sync + 2, 0, sizeof(int)));
+        }
+    }
     if (clear && st) {
         for (int b = 0; b < h->B; ++b) c[(size_t)b * C_WORDS + C_STATUS] = 0;
         HIPCHK(hipMemcpy(h->ctrl[h->cidx], c.data(), sizeof(int) * c.size(), hipMemcpyHostToDevice));
@@ -1271,6 +1293,14 @@ int nuslam_batch_restore(nuslam_batch_t* h, int b, const double* state, const do
     return restore(h, b, state, cov, ld, seen);
 }
 
+#ifdef NUSLAM_DA_CLOCK
+extern "C" int nuslam_debug_da_clock(long long out[64])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_da_clock), sizeof(long long) * 64));
+    return NUSLAM_OK;
+}
+#endif
 #ifdef NUSLAM_CHAIN_CLOCK
 extern "C" int nuslam_debug_chain_clock(long long out[32])
 {
@@ -1352,7 +1382,7 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
-    if (!h || mode < -1 || mode > 1) return NUSLAM_E_ARG;
+    if (!h || mode < -1 || mode > 2) return NUSLAM_E_ARG;
     h->tick_mode = mode;
     return NUSLAM_OK;
 }

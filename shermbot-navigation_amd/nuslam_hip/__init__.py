@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_hip.so")   # override: A/B experiments only
 
-OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY, E_COMM = range(9)
+OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY, E_COMM, E_SYNC = range(10)
 COMM_ID_BYTES = 128
 F64, F32 = 0, 1
 K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2, K_TICK_CHAIN, K_TICK_PANELS, K_TICK_APPLY, K_TICK_NEXT, K_DA_BEGIN, K_DA_STEP = range(13)

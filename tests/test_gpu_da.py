@@ -14,10 +14,17 @@ pytestmark = pytest.mark.gpu
 Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
 
 
-def pair_of_filters(hip, n, dtype=0, Qm=Q):
+@pytest.fixture(params=[1, 2], ids=["resident-round", "launch-per-marker"])
+def pipe(request):
+    """tick mode 1: one resident launch per round (workgroups meet at a device counter between corrections);
+    mode 2: k_da_begin + one k_da_step launch per marker (what large batches take)"""
+    return request.param
+
+
+def pair_of_filters(hip, n, dtype=0, Qm=Q, pipe=1):
     a = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R, dtype=dtype)
     b = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R, dtype=dtype)
-    a.as_batch().set_tick_mode(1)
+    a.as_batch().set_tick_mode(pipe)
     b.as_batch().set_tick_mode(0)               # k_associate + k_update per marker
     return a, b
 
@@ -29,11 +36,11 @@ def same(a, b):
 
 @pytest.mark.parametrize("n,m,dtype,sigma", [(12, 5, 0, 1e-3), (12, 1, 0, 1e-3), (40, 16, 0, 1e-3), (40, 16, 1, 1e-3),
                                              (70, 37, 0, 1e-3), (35, 16, 0, None)])
-def test_da_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype, sigma):
+def test_da_pipeline_equals_per_correction_kernels_cold_start(hip, pipe, n, m, dtype, sigma):
     """sigma None: the simulator's marker noise (sqrt(1e-3) m), where gray-zone verdicts and spurious new landmarks occur."""
     T = 10
     tr = synth.make_trace(n, T, m, straight_every=3, noise_sigma=sigma)
-    a, b = pair_of_filters(hip, n, dtype)
+    a, b = pair_of_filters(hip, n, dtype, pipe=pipe)
     verdicts = []
     for t in range(T):
         try:
@@ -58,13 +65,13 @@ def test_da_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype, 
     assert (v > 0).sum() > 0
 
 
-def test_da_pipeline_new_landmark_gray_zone_and_resighting_in_one_tick(hip):
+def test_da_pipeline_new_landmark_gray_zone_and_resighting_in_one_tick(hip, pipe):
     n, n_world, m, T = 30, 24, 8, 5
     Qs = np.diag([1e-4, 1e-4, 1e-4])
     lm = synth.make_landmarks(n_world)
     tr = synth.make_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
     bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
-    a, b = pair_of_filters(hip, n, 0, Qs)
+    a, b = pair_of_filters(hip, n, 0, Qs, pipe)
     for f in (a, b):
         f.tick(np.zeros(3), bx, by, known_ids=wid)
     assert same(a, b) and a.seen == n_world
@@ -84,13 +91,13 @@ def test_da_pipeline_new_landmark_gray_zone_and_resighting_in_one_tick(hip):
     assert got[1, 3] == n_world + 1 and got[1, 6] == n_world + 1 and got[2, 2] == -1 and got[3, 5] == got[3, 0]
 
 
-def test_da_pipeline_full_map_latches_bounds(hip):
+def test_da_pipeline_full_map_latches_bounds(hip, pipe):
     """seen == n and an unmatched marker: associateLandmark would write past the map (slam_library.cpp:206-207)."""
     n, m = 6, 4
     lm = synth.make_landmarks(n)
     tr = synth.make_trace(n, 2, m, landmarks=lm, noise_sigma=1e-4)
     bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
-    a, b = pair_of_filters(hip, n)
+    a, b = pair_of_filters(hip, n, pipe=pipe)
     codes = []
     for f in (a, b):
         f.tick(np.zeros(3), bx, by, known_ids=wid)
@@ -104,12 +111,12 @@ def test_da_pipeline_full_map_latches_bounds(hip):
 
 
 @pytest.mark.parametrize("B,n,m,dtype", [(3, 20, 6, 0), (5, 33, 16, 0), (2, 16, 16, 1)])
-def test_da_pipeline_batch_run(hip, B, n, m, dtype):
+def test_da_pipeline_batch_run(hip, pipe, B, n, m, dtype):
     T = 8
     traces = [synth.make_trace(n, T, m, seed=700 + k, noise_sigma=1e-3, straight_every=4) for k in range(B)]
     tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces]); my = np.stack([t.my for t in traces])
     out, stats = [], []
-    for mode in (1, 0):
+    for mode in (pipe, 0):
         bt = hip.Batch(B, n, Q, R, dtype=dtype)
         bt.set_tick_mode(mode)
         bt.load_trace(tw, mx, my, None)
@@ -122,7 +129,7 @@ def test_da_pipeline_batch_run(hip, B, n, m, dtype):
         assert out[0][k][2] == out[1][k][2] and out[0][k][2] > 0
 
 
-def test_da_pipeline_device_trace_with_empty_marker_slots(hip):
+def test_da_pipeline_device_trace_with_empty_marker_slots(hip, pipe):
     """A generated trace with a range gate: marker slots without a marker (presence word < 0) are not associated."""
     import nuslam_hip as nh
     B, n, m, T = 4, 24, 8, 12
@@ -130,7 +137,7 @@ def test_da_pipeline_device_trace_with_empty_marker_slots(hip):
     cmd = np.zeros((T, 2)); cmd[:, 0] = 0.1; cmd[:, 1] = 0.05
     sim = nh.SimParams(marker_sigma=1e-3, max_range=1.2)
     out = []
-    for mode in (1, 0):
+    for mode in (pipe, 0):
         bt = hip.Batch(B, n, Q, R)
         bt.set_tick_mode(mode)
         bt.simulate(sim, lm, cmd, m, 4321, first_filter=0, known_ids=False)
@@ -143,7 +150,7 @@ def test_da_pipeline_device_trace_with_empty_marker_slots(hip):
     assert 0 < out[0][0][2] < n, "the range gate must leave some landmarks unseen"
 
 
-def test_da_pipeline_n1000(hip):
+def test_da_pipeline_n1000(hip, pipe):
     """BASELINE configs[4] size: 3 ticks x 16 markers over 998 seen landmarks (34 workgroups per step), one new landmark,
     one gray-zone marker: bitwise the per-correction path."""
     n, n_world, m, T = 1000, 998, 16, 3
@@ -151,7 +158,7 @@ def test_da_pipeline_n1000(hip):
     lm = synth.make_landmarks(n_world)
     tr = synth.make_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
     bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
-    a, b = pair_of_filters(hip, n, 0, Qs)
+    a, b = pair_of_filters(hip, n, 0, Qs, pipe)
     for f in (a, b):
         f.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
     mx, my = tr.mx.copy(), tr.my.copy()
