@@ -41,6 +41,9 @@ struct DaBuf {
     double* Z;       // [B][2][kTickJ] the round's markers in polar form (slam.cpp:286)
     int* keyp;       // [B][kTickJ][nwg] association key of marker s as seen by workgroup w (min over its candidates)
     int nwg;
+    // resident round only:
+    double* AP[2];          // [B][n][16]  what associateLandmark formed for a MATCHING candidate: H (10), psi^-1 (4), z_hat (2)
+    long long* keyt;        // [B][kTickJ][nwg]  (tag << 32) | key: the key slot doubles as the workgroup's arrival flag
 };
 
 // associateLandmark's test of one candidate (slam_library.cpp:209-246) from pb[q][q2] = P(set[q2], set[q]):
@@ -496,49 +499,46 @@ __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int 
 }
 
 // ------------------------------------------------------------------------------------------------ a whole round, resident
-// The same corrections as k_da_begin + J x k_da_step, as ONE launch whose workgroups stay resident and meet at a counter
-// in global memory between corrections (grid of nwg x B workgroups, all of which must be on the chip at once: the host
-// takes this path only while nwg * B fits the CUs, see do_da_rounds).  What a kernel boundary cost per correction --
-// dispatch, the re-load of every thread's tracked entries and of its strips of corrections 0..s-1 -- stays in registers
-// and LDS; what other workgroups need (the tracked entries of whichever landmark is associated next, the strips at its
-// two indices, the candidates' keys) still travels through global memory -- every such store and every such load at
-// agent scope (`sc1`: write-through, L1-bypassing), every storing wave drained (vmcnt(0)) in front of the workgroup
-// barrier behind which ONE lane bumps the counter, the counter polled with an sc1 load, a workgroup barrier between the
-// poll and the loads: the fence-free hand-off of MI355X_MICROARCH.md "Valid forms" (first table row).  An agent-scope
-// release + acquire pair per correction instead (L2 write-back + L1 invalidate, ~1.7 us each) made the resident kernel
-// no faster than one launch per marker.  Every wait is bounded; an expired one latches NUSLAM_E_SYNC in the filter's
-// status word instead of hanging the device.
+// The same corrections as k_da_begin + J x k_da_step, as ONE launch whose workgroups stay resident and meet between
+// corrections (grid of nwg x B workgroups, all of which must be on the chip at once: the host takes this path only while
+// nwg * B fits the CUs, see do_da_rounds).  What a kernel boundary cost per correction -- dispatch, the re-load of every
+// thread's tracked entries and of its strips of corrections 0..s-1 -- stays in registers and LDS; what other workgroups
+// need (the tracked entries of whichever landmark is associated next, the strips at its two indices, the candidates'
+// keys) still travels through global memory -- every such store and every such load at agent scope (`sc1`: write-through,
+// L1-bypassing), every storing wave drained (vmcnt(0)) in front of the workgroup barrier behind which ONE lane stores the
+// workgroup's key slot, tagged with the step: the slot is the arrival flag, polled with sc1 loads, a workgroup barrier
+// between the poll and the loads (the fence-free hand-off of MI355X_MICROARCH.md "Valid forms", first table row).  An
+// agent-scope release + acquire pair per correction instead (L2 write-back + L1 invalidate, ~1.7 us each) made the
+// resident kernel no faster than one launch per marker.  Every wait is bounded; an expired one latches NUSLAM_E_SYNC in
+// the filter's status word instead of hanging the device.
+//
+// What the phase clock (make daclock, tools/exp_da_clock.py) showed per correction, and what was done about it:
+//  * update() recomputes H, S, S^-1 and z_hat that associateLandmark has just formed for the matching candidate from the
+//    same state and covariance (slam_library.cpp:212-218 / :265-270: the same functions on the same inputs, the same
+//    bits).  The candidate lane that matches publishes them (16 numbers); the head of the next correction loads them
+//    instead of redoing the transcendental chain (1.2 us) -- except for a first sighting, whose landmark is initialised
+//    between the two.
+//  * the candidates' own transcendentals (z_hat: three atan2, two sincos) need the new STATE only, not the covariance:
+//    they run on an idle wave while the tracked covariance entries are still being updated; likewise the heading's
+//    re-normalisation, on the head wave instead of one lane of the gain wave.
+//  * the replay of rows / columns c, c+1 through corrections 0..s-1 reads its coefficients from LDS one correction ahead.
 constexpr int kStatusSync = 9;      // NUSLAM_E_SYNC
+constexpr int kDaRoundLds = (kTickJ * 5 + kTickJ * 2 + kTickJ * 5) * kDaSlots * (int)sizeof(double);
 
+#ifdef NUSLAM_DA_EXP_PLAIN
+__device__ inline void st_agent(double* p, double x) { *p = x; }
+#else
 __device__ inline void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline void st_agent(int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+__device__ inline void st_agent(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline double ld_agent(const double* p)
 {
     return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline int ld_agent(const int* p)
+__device__ inline long long ld_agent(const long long* p)
 {
-    return __hip_atomic_load(const_cast<int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(const_cast<long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// every thread of the workgroup: arrive at the filter's counter, wait until it has reached `target`
-__device__ inline bool round_meet(int* cnt, int target)
-{
-    __shared__ int ok_sh;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int ok = 0;
-        for (int it = 0; it < (1 << 20); ++it) {
-            if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        ok_sh = ok;
-    }
-    __syncthreads();
-    return ok_sh != 0;
-}
-constexpr int kDaRoundLds = (kTickJ * 5 + kTickJ * 2) * kDaSlots * (int)sizeof(double);
 
 #ifdef NUSLAM_DA_CLOCK
 __device__ long long g_da_clock[4][16];       // debug builds (make daclock): per wave of workgroup 0, 100 MHz ticks per phase
@@ -549,7 +549,7 @@ __device__ long long g_da_clock[4][16];       // debug builds (make daclock): pe
 template <typename T>
 __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_landmarks, const T* __restrict__ P, DaBuf d,
                                                   TickStep* __restrict__ plan, double* __restrict__ Kbuf,
-                                                  double* __restrict__ Rbuf, int* __restrict__ bar, int bar_base)
+                                                  double* __restrict__ Rbuf, int round_tag)
 {
     const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -559,24 +559,26 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
     TickStep* pl = plan + (size_t)b * kTickJ;
     double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
     double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
-    int* cnt = bar + b;
     const int t = da_index(wg, lane);
     const bool own = lane < 63 && (lane >= 3 || wg == 0);
     const int tr_ = t < L ? t : 0, tc_ = t < ld ? t : 0;
 
     extern __shared__ double da_lds[];
     double* Rl = da_lds;                                   // [kTickJ][5][64]  R_t'(:, t) of this workgroup's columns
-    double* Kl = da_lds + kTickJ * 5 * kDaSlots;           // [kTickJ][2][64]  K_t'(t, :) of its rows
-    __shared__ double hd[20];
+    double* Kl = Rl + kTickJ * 5 * kDaSlots;               // [kTickJ][2][64]  K_t'(t, :) of its rows
+    double* Ml = Kl + kTickJ * 2 * kDaSlots;               // [kTickJ][5][64]  M_t'(t, set_t') of its rows
+    __shared__ double hd[20];                 // Hc[10], Sinv[4], lx, ly, dz0, dz1
     __shared__ int hi[2];
     __shared__ double Mpose[3][6];
-    __shared__ double hist[kTickJ][12];
+    __shared__ double hist[kTickJ][12];       // Hc[10], c, no-correction flag of the corrections so far
     __shared__ double mcL[kTickJ][2][8];
     __shared__ double rcL[kTickJ][2][6];
     __shared__ double rcolL[kDaSlots][5];
     __shared__ double mrowL[kDaSlots][8];
     __shared__ double nTR[kDaSlots][3], nTC[kDaSlots][3], nS[kDaSlots], nTD[kDaLm][4];
     __shared__ double Zl[2][kTickJ];
+    __shared__ double candH[kDaLm][11], candZ[kDaLm][2];
+    __shared__ int meet_sh[2];                // the reduced key of the next marker, whether every workgroup arrived
 
     // ---- prologue (k_da_begin): the tracked entries out of the covariance after predict
     double e3[3] = { 0.0, 0.0, 0.0 }, sv = 0.0;            // wave 0: TR[.][t]; wave 1: TC[.][t] and the state entry
@@ -631,28 +633,22 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
         const int* ci = v.c_in + b * C_WORDS;
         seen = ci[C_SEEN]; cached = ci[C_SEEN_CACHED]; brk = ci[C_BRK]; status = ci[C_STATUS];
     }
+    unsigned live = 0;                                     // corrections so far that changed P
+    int key = kNoKey;                                      // the reduced key of marker st (from the meet)
 
     for (int st = -1; st < J; ++st) {
+        const bool last = st + 1 == J;
+        bool nocorr = true;
+        int c = 3;
+        double m5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, bef = 0.0, aft = 0.0;  // wave 1: M_s(t, set_s)
         if (st >= 0) {
             const int par = st & 1;
             const double* TRc = d.TR[par] + (size_t)b * 3 * ld;
-            double* TRn = d.TR[par ^ 1] + (size_t)b * 3 * ld;
             const double* TCc = d.TC[par] + (size_t)b * 3 * ld;
-            double* TCn = d.TC[par ^ 1] + (size_t)b * 3 * ld;
             const double* TDc = d.TD[par] + (size_t)b * 4 * n;
-            double* TDn = d.TD[par ^ 1] + (size_t)b * 4 * n;
             const double* sc = d.DS[par] + (size_t)b * ld;
-            double* sn = d.DS[par ^ 1] + (size_t)b * ld;
-            const bool last = st + 1 == J;
-
             DCK(0);
-            // ---- the decision, by every wave
-            int key = kNoKey;
-            for (int i = lane; i < nwg; i += 64) {
-                const int kk = ld_agent(&d.keyp[((size_t)b * kTickJ + st) * nwg + i]);
-                key = kk < key ? kk : key;
-            }
-            key = wave_min(key);
+            // ---- the decision, by every thread: associateLandmark's verdict, then slam.cpp:295-316
             int id_raw, seen_now, status_now;
             {
                 const Assoc a = decode_association(n, seen, brk, status, key);
@@ -660,12 +656,14 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 if (o.ids != nullptr && o.ids[b * o.stride + o.off + st] < 0) { id_raw = -1; seen_now = seen; status_now = status; }
             }
             const Decision dd = resolve(n, id_raw, seen_now, cached, brk, status_now, MODE_DA, total_landmarks);
-            const int c = dd.c;
+            c = dd.c;
             const int setv[5] = { 0, 1, 2, c, c + 1 };
+            const bool matched = !dd.skip && !dd.init;     // update() of a landmark associateLandmark has just examined
             DCK(1);
 
             // ---- loads that depend on the landmark
             double g0 = 0.0, g1 = 0.0;
+            double th_old = 0.0, kp0 = 0.0, kp1 = 0.0;     // wave 2: the heading before, K_s(0, :)
             if (wave == 0) {
                 g0 = (double)Pb[(size_t)tr_ * ld + c];
                 g1 = (double)Pb[(size_t)tr_ * ld + c + 1];
@@ -673,6 +671,8 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 g0 = (double)Pb[(size_t)c * ld + tc_];
                 g1 = (double)Pb[(size_t)(c + 1) * ld + tc_];
             } else if (wave == 2) {
+                // lane 5 q + q2 < 25: P_{s-1}(set[q2], set[q]); lanes 32..36: th, x, y, lx, ly; lanes 40..55: the matching
+                // candidate's H, psi^-1, z_hat
                 const int e = lane < 25 ? lane : 0;
                 const int q = e / 5, q2 = e % 5;
                 const double* src;
@@ -681,22 +681,28 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 else src = TDc + (size_t)((q2 - 3) + 2 * (q - 3)) * n + (c - 3) / 2;
                 const int sl = lane - 32;
                 if (sl >= 0 && sl < 5) src = sc + setv[sl];
+                if (matched && sl >= 8 && sl < 24) src = d.AP[par] + ((size_t)b * n + (c - 3) / 2) * 16 + (sl - 8);
                 const double val = ld_agent(src);
                 const double th = lane_bcast(val, 32), x = lane_bcast(val, 33), y = lane_bcast(val, 34);
                 double lx = lane_bcast(val, 35), ly = lane_bcast(val, 36);
                 const double r = Zl[0][st], phi = Zl[1][st];
                 bool skip0 = dd.skip;
                 int stt = dd.new_status;
-                double Hc[10], Si[4];
+                double Hc[10], Si[4], dz0 = 0.0, dz1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 10; ++k) Hc[k] = 0.0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) Si[k] = 0.0;
-                if (!skip0) {
-                    if (dd.init) {                                      // initializeLandmark, slam_library.cpp:255-261
-                        lx = x + r * cos(phi + th);
-                        ly = y + r * sin(phi + th);
-                    }
+                if (matched) {
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) Hc[k] = lane_bcast(val, 40 + k);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) Si[k] = lane_bcast(val, 50 + k);
+                    dz0 = r - lane_bcast(val, 54);                      // :272, bearing innovation not wrapped
+                    dz1 = phi - lane_bcast(val, 55);
+                } else if (!skip0) {
+                    lx = x + r * cos(phi + th);                         // initializeLandmark, slam_library.cpp:255-261
+                    ly = y + r * sin(phi + th);
                     double pb[5][5], S[4];
 #pragma unroll
                     for (int a = 0; a < 5; ++a)
@@ -705,27 +711,36 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     jacobian_compact(x, y, lx, ly, Hc);                 // :268
                     innovation_cov_block(pb, Hc, v.R, S);               // :270
                     if (inv2(S, Si)) { skip0 = true; if (stt == 0) stt = kStatusSingular; }
-                    double pc[5];
+                    double zr, zb;
+                    measurement(th, x, y, lx, ly, zr, zb);              // :265
+                    dz0 = r - zr;
+                    dz1 = phi - zb;
+                }
+                if (!skip0) {
+                    double pc[5], K[2], m[5];                           // the gain rows of the pose: pc[a2] = P(lane, set[a2])
 #pragma unroll
                     for (int a2 = 0; a2 < 5; ++a2) pc[a2] = __shfl(val, 5 * a2 + (lane < 3 ? lane : 0), 64);
-                    if (!skip0 && lane < 3) {
-                        double K[2], m[5];
-                        gain_row(pc, Hc, Si, lane, setv, K, m);
+                    gain_row(pc, Hc, Si, lane < 3 ? lane : 0, setv, K, m);
+                    if (lane < 3) {
 #pragma unroll
                         for (int a2 = 0; a2 < 5; ++a2) Mpose[lane][a2] = m[a2];
                     }
+                    kp0 = lane_bcast(K[0], 0);
+                    kp1 = lane_bcast(K[1], 0);
                 }
+                th_old = th;
                 if (lane == 0) {
 #pragma unroll
                     for (int k = 0; k < 10; ++k) hd[k] = Hc[k];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hd[10 + k] = Si[k];
-                    hd[14] = lx; hd[15] = ly;
+                    hd[14] = lx; hd[15] = ly; hd[16] = dz0; hd[17] = dz1;
                     hi[0] = skip0 ? 1 : 0; hi[1] = stt;
                 }
             } else {
+                // lanes (t', e): the coefficients of rows / columns c + e through correction t'
                 const int tp = lane >> 1, e = lane & 1;
-                if (lane < 2 * kTickJ && tp < st) {
+                if (lane < 2 * kTickJ && tp < st && !dd.skip) {
                     const int cp = (int)hist[tp][10];
                     const int i = c + e;
                     const double K0 = ld_agent(&Kb[(size_t)(tp * 2 + 0) * ld + i]), K1 = ld_agent(&Kb[(size_t)(tp * 2 + 1) * ld + i]);
@@ -744,22 +759,12 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     mcL[tp][e][5] = (i > 2 && i < cp) ? 1.0 : 0.0;
                     mcL[tp][e][6] = (i > cp + 1) ? 1.0 : 0.0;
                 }
-                if (!dd.skip) {
-                    const double th = ld_agent(&sc[0]), x = ld_agent(&sc[1]), y = ld_agent(&sc[2]);
-                    const double r = Zl[0][st], phi = Zl[1][st];
-                    double lx, ly;
-                    if (dd.init) { lx = x + r * cos(phi + th); ly = y + r * sin(phi + th); }
-                    else { lx = ld_agent(&sc[c]); ly = ld_agent(&sc[c + 1]); }
-                    double zr, zb;
-                    measurement(th, x, y, lx, ly, zr, zb);
-                    if (lane == 0) { hd[16] = r - zr; hd[17] = phi - zb; }
-                }
             }
             DCK(2);
             __syncthreads();
             DCK(3);
 
-            const bool nocorr = hi[0] != 0;
+            nocorr = hi[0] != 0;
             const int new_status = hi[1];
             const double lx = hd[14], ly = hd[15];
             double Hc[10], Si[4];
@@ -768,17 +773,29 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
 #pragma unroll
             for (int k = 0; k < 4; ++k) Si[k] = hd[10 + k];
             double n3[3] = { e3[0], e3[1], e3[2] };
-            double m5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, bef = 0.0, aft = 0.0;
 
             if (wave == 0) {
                 if (!nocorr) {
-                    for (int tp = 0; tp < st; ++tp) {
-                        if (hist[tp][11] == 0.0) {
-                            double r[5];
+                    // rows c, c+1 of P_{s-1} at column t: the gathered entries replayed through corrections 0..s-1, two
+                    // corrections per trip so that the second one's coefficients are on their way from LDS while the first
+                    // is applied (a register-rotating prefetch cost more in moves than it hid)
+                    unsigned todo = live;
+                    while (todo) {
+                        const int ta = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const bool two = todo != 0;
+                        const int tb = two ? __builtin_ctz(todo) : ta;
+                        if (two) todo &= todo - 1;
+                        double ra[5], rb[5], ma[7], mb[7], na[7], nb[7];
 #pragma unroll
-                            for (int q = 0; q < 5; ++q) r[q] = Rl[(tp * 5 + q) * kDaSlots + lane];
-                            g0 = p1_entry<T>(mcL[tp][0], r, g0, mcL[tp][0][5], mcL[tp][0][6]);
-                            g1 = p1_entry<T>(mcL[tp][1], r, g1, mcL[tp][1][5], mcL[tp][1][6]);
+                        for (int q = 0; q < 5; ++q) { ra[q] = Rl[(ta * 5 + q) * kDaSlots + lane]; rb[q] = Rl[(tb * 5 + q) * kDaSlots + lane]; }
+#pragma unroll
+                        for (int q = 0; q < 7; ++q) { ma[q] = mcL[ta][0][q]; mb[q] = mcL[ta][1][q]; na[q] = mcL[tb][0][q]; nb[q] = mcL[tb][1][q]; }
+                        g0 = p1_entry<T>(ma, ra, g0, ma[5], ma[6]);
+                        g1 = p1_entry<T>(mb, ra, g1, mb[5], mb[6]);
+                        if (two) {
+                            g0 = p1_entry<T>(na, rb, g0, na[5], na[6]);
+                            g1 = p1_entry<T>(nb, rb, g1, nb[5], nb[6]);
                         }
                     }
                     const double rs[5] = { e3[0], e3[1], e3[2], g0, g1 };
@@ -786,40 +803,43 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     for (int q = 0; q < 5; ++q) {
                         Rl[(st * 5 + q) * kDaSlots + lane] = rs[q];
                         rcolL[lane][q] = rs[q];
-                        if (own && t < L) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rs[q]);
                     }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(Mpose[q], rs, e3[q], 0.0, 0.0);
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    if (own && t < L) st_agent(&TRn[(size_t)q * ld + t], n3[q]);
                     nTR[lane][q] = n3[q];
                     e3[q] = n3[q];
                 }
             } else if (wave == 1) {
                 double snew = sv;
-                if (dd.init && !dd.skip) {
+                if (dd.init && !dd.skip) {                              // initializeLandmark ran (also when update() then threw)
                     if (t == c) snew = lx;
                     if (t == c + 1) snew = ly;
                 }
                 if (!nocorr) {
-                    for (int tp = 0; tp < st; ++tp) {
-                        if (hist[tp][11] == 0.0) {
-                            const int cp = (int)hist[tp][10];
-                            const double K0 = Kl[(tp * 2 + 0) * kDaSlots + lane], K1 = Kl[(tp * 2 + 1) * kDaSlots + lane];
-                            double mt[5];
+                    unsigned todo = live;
+                    while (todo) {
+                        const int ta = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const bool two = todo != 0;
+                        const int tb = two ? __builtin_ctz(todo) : ta;
+                        if (two) todo &= todo - 1;
+                        double mta[5], mtb[5], ra0[5], ra1[5], rb0[5], rb1[5];
 #pragma unroll
-                            for (int q = 0; q < 5; ++q) {
-                                double kh = 0.0;
-                                kh = fma(K0, hist[tp][0 + 2 * q], kh);
-                                kh = fma(K1, hist[tp][1 + 2 * q], kh);
-                                const int sidx = q < 3 ? q : cp + (q - 3);
-                                mt[q] = (t == sidx ? 1.0 : 0.0) - kh;
-                            }
-                            const double bp = (t > 2 && t < cp) ? 1.0 : 0.0, ap = (t > cp + 1) ? 1.0 : 0.0;
-                            g0 = p1_entry<T>(mt, rcL[tp][0], g0, bp, ap);
-                            g1 = p1_entry<T>(mt, rcL[tp][1], g1, bp, ap);
+                        for (int q = 0; q < 5; ++q) {
+                            mta[q] = Ml[(ta * 5 + q) * kDaSlots + lane]; mtb[q] = Ml[(tb * 5 + q) * kDaSlots + lane];
+                            ra0[q] = rcL[ta][0][q]; ra1[q] = rcL[ta][1][q]; rb0[q] = rcL[tb][0][q]; rb1[q] = rcL[tb][1][q];
+                        }
+                        const int cpa = (int)hist[ta][10], cpb = (int)hist[tb][10];
+                        const double bpa = (t > 2 && t < cpa) ? 1.0 : 0.0, apa = (t > cpa + 1) ? 1.0 : 0.0;
+                        const double bpb = (t > 2 && t < cpb) ? 1.0 : 0.0, apb = (t > cpb + 1) ? 1.0 : 0.0;
+                        g0 = p1_entry<T>(mta, ra0, g0, bpa, apa);
+                        g1 = p1_entry<T>(mta, ra1, g1, bpa, apa);
+                        if (two) {
+                            g0 = p1_entry<T>(mtb, rb0, g0, bpb, apb);
+                            g1 = p1_entry<T>(mtb, rb1, g1, bpb, apb);
                         }
                     }
                     const double pc[5] = { e3[0], e3[1], e3[2], g0, g1 };
@@ -829,27 +849,34 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     aft = (t > c + 1) ? 1.0 : 0.0;
                     Kl[(st * 2 + 0) * kDaSlots + lane] = K[0];
                     Kl[(st * 2 + 1) * kDaSlots + lane] = K[1];
-                    if (own && t < ld) {
-                        st_agent(&Kb[(size_t)(st * 2 + 0) * ld + t], K[0]);
-                        st_agent(&Kb[(size_t)(st * 2 + 1) * ld + t], K[1]);
-                    }
-                    double acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { Ml[(st * 5 + q) * kDaSlots + lane] = m5[q]; mrowL[lane][q] = m5[q]; }
+                    mrowL[lane][5] = bef; mrowL[lane][6] = aft;
+                    double acc = 0.0;                                   // state += K (z - z_hat)  (:275)
                     acc = fma(K[0], hd[16], acc);
                     acc = fma(K[1], hd[17], acc);
                     snew = snew + acc;
-                    if (t == 0) snew = normalize_angle(snew);
+                }
+                if (t != 0) {                                           // (the heading: wave 2, which re-normalises it, :276)
+                    nS[lane] = snew;
+                    sv = snew;
+                }
+            } else if (wave == 2) {
+                double th = th_old;
+                if (!nocorr) {
+                    double acc = 0.0;
+                    acc = fma(kp0, hd[16], acc);
+                    acc = fma(kp1, hd[17], acc);
+                    th = normalize_angle(th + acc);                     // :275-276
+                }
+                if (lane == 0) nS[0] = th;
+            } else if (lane == 0) {
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) mrowL[lane][q] = m5[q];
-                    mrowL[lane][5] = bef; mrowL[lane][6] = aft;
-                }
-                if (own && t < ld) {
-                    st_agent(&sn[t], snew);
-                    if (last) v.s_out[(size_t)b * ld + t] = snew;
-                }
-                nS[lane] = snew;
-                sv = snew;
-            } else if (wave == 3 && lane == 0) {
+                for (int k = 0; k < 10; ++k) hist[st][k] = Hc[k];
+                hist[st][10] = (double)c;
+                hist[st][11] = nocorr ? 1.0 : 0.0;
                 if (wg == 0) {
+                    // the correction's record for the pass over P, the control words, the id log
                     TickStep* ps = pl + st;
                     ps->skip = nocorr ? 1 : 0; ps->init = (dd.init && !dd.skip) ? 1 : 0; ps->c = c; ps->id = dd.id;
 #pragma unroll
@@ -864,29 +891,49 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     if (v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = dd.id;
                 }
             }
+            if (!nocorr) live |= 1u << st;
+            seen = dd.new_seen; brk = dd.new_brk; status = new_status;
             DCK(4);
-            __syncthreads();
-            DCK(5);
-            if (wave == 3 && lane == 0) {                               // (after the barrier: wave 3's lanes were still reading hist)
-#pragma unroll
-                for (int k = 0; k < 10; ++k) hist[st][k] = Hc[k];
-                hist[st][10] = (double)c;
-                hist[st][11] = nocorr ? 1.0 : 0.0;
-            }
+        }
+        __syncthreads();
+        DCK(5);
+        if (wave == 1 && t == 0) sv = nS[0];
 
-            if (wave == 1) {
+        // ---- waves 0, 1: columns 0..2 at this row (needs the row role's strips of slots 0..2) and the diagonal blocks;
+        // ---- waves 2, 3: what the next marker's candidates need of the new STATE: H (wave 2), z_hat (wave 3)
+        const bool cand = !last && !(brk || seen == 0 || seen >= n) && lane < kDaLm && wg * kDaLm + lane + 1 <= seen;
+        const int s0 = 3 + 2 * (lane < kDaLm ? lane : 0);               // slot of the candidate's first index
+        if (st >= 0 && wave == 1) {
+            const int par = st & 1;
+            double* TCn = d.TC[par ^ 1] + (size_t)b * 3 * ld;
+            double n3[3] = { e3[0], e3[1], e3[2] };
+            if (!nocorr) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (own && t < ld) st_agent(&TCn[(size_t)q * ld + t], n3[q]);
+                nTC[lane][q] = n3[q];
+                e3[q] = n3[q];
+            }
+            // (the stores of a correction are dealt over waves 0..2: each costs its wave ~0.1 us of issue, and wave 3's
+            // z_hat chain, ~1.3 us, is what this phase has to wait for anyway)
+            if (own && t < ld) {
+                double* sn = d.DS[par ^ 1] + (size_t)b * ld;
                 if (!nocorr) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
+                    st_agent(&Kb[(size_t)(st * 2 + 0) * ld + t], Kl[(st * 2 + 0) * kDaSlots + lane]);
+                    st_agent(&Kb[(size_t)(st * 2 + 1) * ld + t], Kl[(st * 2 + 1) * kDaSlots + lane]);
                 }
+                st_agent(&sn[t], sv);
+                if (last) v.s_out[(size_t)b * ld + t] = sv;
+            }
+        } else if (st >= 0 && wave == 0) {
+            const int par = st & 1;
+            double* TDn = d.TD[par ^ 1] + (size_t)b * 4 * n;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (own && t < ld) st_agent(&TCn[(size_t)q * ld + t], n3[q]);
-                    nTC[lane][q] = n3[q];
-                    e3[q] = n3[q];
-                }
-            } else if (wave == 0 || wave == 2) {
-                const int idx = (wave == 0 ? 0 : 64) + lane;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int idx = 64 * h2 + lane;                         // entry e of landmark lm: P(c_lm + (e & 1), c_lm + (e >> 1))
                 const int lm = idx >> 2, e = idx & 3;
                 const int k = wg * kDaLm + lm;
                 if (lm < kDaLm && k < n) {
@@ -897,23 +944,44 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     nTD[lm][e] = val;
                 }
             }
-            seen = dd.new_seen; brk = dd.new_brk; status = new_status;
-            DCK(6);
-            if (last) break;
-            __syncthreads();
-            DCK(7);
-        } else {
-            __syncthreads();
+            if (own && t < L && !nocorr) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rcolL[lane][q]);
+            }
+        } else if (wave == 2) {
+            if (cand) {
+                double Hc[10];
+                jacobian_compact(nS[1], nS[2], nS[s0], nS[s0 + 1], Hc);                    // :212
+#pragma unroll
+                for (int k = 0; k < 10; ++k) candH[lane][k] = Hc[k];
+            }
+            if (st >= 0) {
+                // rows 0..2 at this column go out from here, off the prior-row wave's critical path
+                const int par = st & 1;
+                double* TRn = d.TR[par ^ 1] + (size_t)b * 3 * ld;
+                if (own && t < L) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) st_agent(&TRn[(size_t)q * ld + t], nTR[lane][q]);
+                }
+            }
+        } else if (wave == 3) {
+            if (cand) {
+                double zr, zb;
+                measurement(nS[0], nS[1], nS[2], nS[s0], nS[s0 + 1], zr, zb);              // :218
+                candZ[lane][0] = zr; candZ[lane][1] = zb;
+            }
         }
+        DCK(6);
+        if (last) break;
+        __syncthreads();
+        DCK(7);
 
         // ---- the candidates of marker st + 1 against what this correction (or the prologue) left: k_associate
         if (wave == 0) {
             int key1 = kNoKey;
-            const int k1 = wg * kDaLm + lane + 1;
-            if (!(brk || seen == 0 || seen >= n) && lane < kDaLm && k1 <= seen) {
+            if (cand) {
                 const double r = Zl[0][st + 1], phi = Zl[1][st + 1];
-                const int s0 = 3 + 2 * lane;
-                double pb[5][5];
+                double pb[5][5], Hc[10], psi[4], psi_inv[4];            // pb[q][q2] = P(set[q2], set[q])
 #pragma unroll
                 for (int q = 0; q < 5; ++q)
 #pragma unroll
@@ -924,16 +992,67 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                         else val = nTD[lane][(q2 - 3) + 2 * (q - 3)];
                         pb[q][q2] = val;
                     }
-                const int code = assoc_code(pb, v.R, nS[0], nS[1], nS[2], nS[s0], nS[s0 + 1], r, phi);
-                if (code >= 0) key1 = k1 * 4 + code;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) Hc[k] = candH[lane][k];
+                const double zr = candZ[lane][0], zb = candZ[lane][1];
+                innovation_cov_block(pb, Hc, v.R, psi);                 // :215
+                const double dz0 = r - zr, dz1 = phi - zb;             // :229
+                int code = -1;
+                if (inv2(psi, psi_inv)) code = 2;
+                else {
+                    double w0 = 0.0, w1 = 0.0, dd2 = 0.0;               // (dz^T psi^-1) dz, :231
+                    w0 = fma(dz0, psi_inv[0], w0); w0 = fma(dz1, psi_inv[1], w0);
+                    w1 = fma(dz0, psi_inv[2], w1); w1 = fma(dz1, psi_inv[3], w1);
+                    dd2 = fma(w0, dz0, dd2); dd2 = fma(w1, dz1, dd2);
+                    if (dd2 < 0.01) code = 0;                                           // :238
+                    else if ((dd2 > 0.01) && (dd2 < 60)) code = 1;                      // :243
+                }
+                if (code >= 0) key1 = (wg * kDaLm + lane + 1) * 4 + code;
+                if (code == 0) {
+                    // a match: update() will want exactly these (same state, same covariance, same functions)
+                    double* ap = d.AP[(st + 1) & 1] + ((size_t)b * n + wg * kDaLm + lane) * 16;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) st_agent(ap + k, Hc[k]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) st_agent(ap + 10 + k, psi_inv[k]);
+                    st_agent(ap + 14, zr);
+                    st_agent(ap + 15, zb);
+                }
             }
             key1 = wave_min(key1);
-            if (lane == 0) st_agent(&d.keyp[((size_t)b * kTickJ + st + 1) * nwg + wg], key1);
+            meet_sh[0] = key1;                                          // (every lane holds the minimum)
         }
-        // ---- meet the other workgroups of this filter: everything stored above is published, everything they stored is
-        // visible behind the wait
         DCK(8);
-        if (!round_meet(cnt, bar_base + nwg * (st + 2)) && status == 0) status = kStatusSync;
+        // ---- meet the other workgroups of this filter: everything stored above has left, then the tagged key slot; the
+        // slots of all workgroups are polled until they carry this step's tag
+        {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int tag = round_tag + st + 2;
+            long long* slots = d.keyt + ((size_t)b * kTickJ + st + 1) * nwg;
+            if (wave == 0) {
+                if (lane == 0) st_agent(slots + wg, ((long long)tag << 32) | (unsigned)meet_sh[0]);
+                int kmin = kNoKey, ok = 1;
+                for (int i = lane; i < nwg; i += 64) {
+                    long long w = 0;
+                    int got = 0;
+                    for (int it = 0; it < (1 << 20); ++it) {
+                        w = ld_agent(slots + i);
+                        if ((int)(w >> 32) == tag) { got = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    ok &= got;
+                    const int kk = (int)(unsigned)(w & 0xffffffffll);
+                    kmin = kk < kmin ? kk : kmin;
+                }
+                kmin = wave_min(kmin);
+                ok = __all(ok);
+                if (lane == 0) { meet_sh[0] = kmin; meet_sh[1] = ok; }
+            }
+            __syncthreads();
+            key = meet_sh[0];
+            if (!meet_sh[1] && status == 0) status = kStatusSync;
+        }
         DCK(9);
     }
 #ifdef NUSLAM_DA_CLOCK

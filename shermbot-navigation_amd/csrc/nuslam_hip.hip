@@ -91,8 +91,7 @@ struct nuslam_batch {
     // unknown association (ekf_da.h): tracked rows / columns / diagonal blocks of P, one launch per correction
     DaBuf da = {};
     void* da_mem = nullptr;
-    int* da_bar = nullptr;     // [B] arrival counters of the resident round kernel (monotonic, never reset)
-    unsigned da_bar_seq = 0;   // their value when every round enqueued so far has passed
+    unsigned da_round_tag = 0; // resident round kernel: tags of the key slots, kTickJ + 1 per round (slots are never reset)
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
     int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
@@ -481,8 +480,9 @@ int ensure_da_buffers(nuslam_batch* h)
     const size_t B = h->B, ld = h->ld, n = h->n;
     const int nwg = (h->ld - 3 + kDaOwn - 1) / kDaOwn > 0 ? (h->ld - 3 + kDaOwn - 1) / kDaOwn : 1;
     // one allocation: 2 x (TR, TC) [B][3][ld], 2 x TD [B][4][n], 2 x DS [B][ld], Z [B][2][kTickJ]; then the int arrays
-    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ;
-    const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg + B;
+    // ... AP 2 x [B][n][16], keyt [B][kTickJ][nwg] (8-byte words)
+    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ + 2 * B * n * 16 + B * kTickJ * (size_t)nwg;
+    const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg;
     HIPCHK(hipMalloc(&h->da_mem, nd * sizeof(double) + ni * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->da_mem, 0, nd * sizeof(double) + ni * sizeof(int), h->stream));
     double* p = (double*)h->da_mem;
@@ -491,10 +491,11 @@ int ensure_da_buffers(nuslam_batch* h)
     for (int k = 0; k < 2; ++k) { h->da.TD[k] = p; p += B * 4 * n; }
     for (int k = 0; k < 2; ++k) { h->da.DS[k] = p; p += B * ld; }
     h->da.Z = p; p += B * 2 * kTickJ;
+    for (int k = 0; k < 2; ++k) { h->da.AP[k] = p; p += B * n * 16; }
+    h->da.keyt = (long long*)p; p += B * kTickJ * (size_t)nwg;
     int* q = (int*)p;
     for (int k = 0; k < 2; ++k) { h->da.DC[k] = q; q += B * C_WORDS; }
-    h->da.keyp = q; q += B * kTickJ * (size_t)nwg;
-    h->da_bar = q;
+    h->da.keyp = q;
     h->da.nwg = nwg;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
@@ -516,9 +517,9 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
         const bool resident = h->tick_mode != 2 && (long long)h->da.nwg * h->B <= h->n_cu;
         if (resident) {
             DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T>, grid, block, (size_t)kDaRoundLds, v, o, total,
-                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, h->da_bar, (int)h->da_bar_seq)));
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, (int)h->da_round_tag)));
             if (rc) return rc;
-            h->da_bar_seq += (unsigned)h->da.nwg * (unsigned)o.J;     // every workgroup arrives once per marker
+            h->da_round_tag += kTickJ + 1;
         } else {
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_BEGIN, k_da_begin<T>, grid, block, v, o, (const T*)h->P(), h->da)));
             if (rc) return rc;
