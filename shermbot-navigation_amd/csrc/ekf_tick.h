@@ -774,32 +774,51 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
 }
 
 // ------------------------------------------------------------------------------------------------ the pass over P
-// Tiling as k_update: a wave owns 64*VEC consecutive rows x 16 columns, a lane moves 16 bytes per column; WAVES column
-// strips per workgroup.  Everything the J corrections need besides the tile is staged in LDS ONCE, in one burst of loads
+// Tiling as k_update: a wave owns 64*RPL consecutive rows x 16 (or 8) columns, a lane moves 16 (or 32) bytes per column;
+// WAVES column strips per workgroup.  Everything the J corrections need besides the tile is staged in LDS ONCE, in one burst of loads
 // issued ahead of the tile's: K_s at the workgroup's rows (J x 2 x 64*VEC doubles, shared by its waves) and R_s at each
 // wave's 16 columns (J x 5 x 16 doubles per wave).  The loop over the corrections then touches only LDS and registers:
 // per correction and lane two 16-byte reads of K, ten FMAs per row for M(i, set), and per column five broadcast reads of
 // R and seven FMAs per element -- the FMA chain of k_update, operation for operation.
-template <typename T, int WAVES>
+// the chain's last operation, p <- after * p + acc: for fp64 storage written onto the tile's own register (the loop over
+// the corrections carries the tile in fixed registers; the compiler's v_fmac form lands in the accumulator and cost one
+// v_mov_b64 per element and correction to bring it home: 32 of ~300 vector instructions)
+template <typename T>
+__device__ inline void last_term(T& p, double after, double pij, double acc) { p = (T)fma(after, pij, acc); }
+template <>
+__device__ inline void last_term<double>(double& p, double after, double, double acc)
+{
+    asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p) : "v"(after), "v"(acc));
+}
+
+// RPL = rows per lane: 16 bytes' worth (2 for fp64, 4 for fp32; 16 columns per wave); the kernel also instantiates with
+// 4 rows of fp64 (two 16-byte loads per column, 8 columns per wave: half the LDS broadcast reads of R per FMA).  That
+// variant measured SLOWER at len = 2003, J = 16 (36.3 against 33.7 us): the pass is not LDS-bound.  What it is: ~15 us
+// that do not depend on J (staging K and R, the tile's loads, its stores -- none of it overlapped with arithmetic,
+// because the eight waves of a CU move in step) plus ~1.4 us per correction (fp64 FMA issue: 224 chain FMAs + ~80 other
+// vector instructions per wave and correction, two waves per SIMD), against 11.4 us of pure FMA issue for J = 16.
+template <typename T, int WAVES, int RPL>
 __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const TickStep* __restrict__ plan,
                                                            const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
                                                            const T* __restrict__ Pin, T* __restrict__ Pout)
 {
-    constexpr int CW = 16;
     typedef Pack16<T> vec_t;
     typedef Pack16<double> d2_t;
-    constexpr int VEC = 16 / sizeof(T);
-    constexpr int ROWS = 64 * VEC;                        // rows of a workgroup
+    constexpr int VEC = 16 / sizeof(T);                   // elements per 16-byte vector
+    constexpr int NV = RPL / VEC;                         // vectors per column and lane
+    static_assert(NV == 1 || NV == 2, "a lane owns 16 or 32 bytes of every column");
+    constexpr int CW = NV == 1 ? 16 : 8;                  // columns of a wave
+    constexpr int ROWS = 64 * RPL;                        // rows of a workgroup
     const int b = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ld = v.ld, L = v.L;
     const int rbase = blockIdx.x * ROWS;
-    const int row0 = rbase + lane * VEC;
+    const int row0 = rbase + lane * RPL;
     const int strip = blockIdx.y * WAVES + wave;
     const bool active = strip * CW < L;
     const int j0 = active ? strip * CW : 0;
-    const bool rows_ok = row0 < ld;
+    const bool rows_ok = row0 < ld;                       // (ld is a multiple of 32 >= RPL: a lane's rows are all inside or all outside)
     const int rowc = rows_ok ? row0 : 0;
     const int ncol = (L - j0) < CW ? (L - j0) : CW;
     const TickStep* pl = plan + (size_t)b * kTickJ;
@@ -822,7 +841,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
         gr = gr < ld ? gr : 0;                            // rows past the padded length: any readable address (never used)
         kst[i] = *reinterpret_cast<const d2_t*>(Kb + (size_t)row * ld + gr);
     }
-    constexpr int RCH = kTickJ * 5 * CW / 2 / 64;         // = 10 chunks of R per lane, at most
+    constexpr int RCH = (kTickJ * 5 * CW / 2 + 63) / 64;  // 16-byte chunks of R per lane, at most
     d2_t rst[RCH];
     const double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld + j0;
     const int nr = J * 5 * (CW / 2);
@@ -835,9 +854,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
         rst[i] = *reinterpret_cast<const d2_t*>(Rb + (size_t)row * ld + 2 * piece);
     }
     const T* Pr = Pin + (size_t)b * v.p_stride + (size_t)j0 * ld + rowc;
-    vec_t p[CW];
+    vec_t p[CW][NV];
 #pragma unroll
-    for (int jj = 0; jj < CW; ++jj) p[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+    for (int jj = 0; jj < CW; ++jj)
+#pragma unroll
+        for (int nv = 0; nv < NV; ++nv) p[jj][nv] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld + nv * VEC);
 #pragma unroll
     for (int i = 0; i < KCH; ++i) {
         const int k = threadIdx.x + i * 64 * WAVES;
@@ -869,11 +890,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
             for (int q = 0; q < 10; ++q) nH[q] = pn->Hc[q];
         }
         if (skip) continue;                               // wave-uniform
-        double m[VEC][5], bef[VEC], aft[VEC];
+        double m[RPL][5], bef[RPL], aft[RPL];
 #pragma unroll
-        for (int e = 0; e < VEC; e += 2) {
-            const d2_t k0 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 0) * ROWS + lane * VEC + e);
-            const d2_t k1 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 1) * ROWS + lane * VEC + e);
+        for (int e = 0; e < RPL; e += 2) {
+            const d2_t k0 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 0) * ROWS + lane * RPL + e);
+            const d2_t k1 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 1) * ROWS + lane * RPL + e);
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int i = row0 + e + h2;
@@ -893,20 +914,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
         // the prior rows of eight columns at a time, as 20 broadcast ds_read_b128 issued together (one dependent
         // read-then-FMA group per column left the loop waiting on LDS latency sixteen times per correction)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < CW / 8; ++half) {
             d2_t rr[5][4];
 #pragma unroll
             for (int q = 0; q < 5; ++q)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) rr[q][k] = *reinterpret_cast<const d2_t*>(Rst + q * CW + half * 8 + 2 * k);
-            // sweep_entry's chain, written stage by stage over the 8 x VEC independent elements: seven dependent FMAs
+            // sweep_entry's chain, written stage by stage over the 8 x RPL independent elements: seven dependent FMAs
             // per element, sixteen (or thirty-two) chains in flight
-            double acc[8][VEC], pij[8][VEC];
+            double acc[8][RPL], pij[8][RPL];
 #pragma unroll
             for (int j8 = 0; j8 < 8; ++j8)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    pij[j8][e] = (double)p[half * 8 + j8].v[e];
+                for (int e = 0; e < RPL; ++e) {
+                    pij[j8][e] = (double)p[half * 8 + j8][e / VEC].v[e % VEC];
                     acc[j8][e] = m[e][0] * rr[0][j8 >> 1].v[j8 & 1];
                 }
 #pragma unroll
@@ -914,28 +935,31 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
 #pragma unroll
                 for (int j8 = 0; j8 < 8; ++j8)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+                    for (int e = 0; e < RPL; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
 #pragma unroll
             for (int j8 = 0; j8 < 8; ++j8)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(bef[e], pij[j8][e], acc[j8][e]);
+                for (int e = 0; e < RPL; ++e) acc[j8][e] = fma(bef[e], pij[j8][e], acc[j8][e]);
 #pragma unroll
             for (int q = 3; q < 5; ++q)
 #pragma unroll
                 for (int j8 = 0; j8 < 8; ++j8)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+                    for (int e = 0; e < RPL; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
 #pragma unroll
             for (int j8 = 0; j8 < 8; ++j8)
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) p[half * 8 + j8].v[e] = (T)fma(aft[e], pij[j8][e], acc[j8][e]);
+                for (int e = 0; e < RPL; ++e) last_term(p[half * 8 + j8][e / VEC].v[e % VEC], aft[e], pij[j8][e], acc[j8][e]);
         }
     }
     if (!rows_ok) return;
     T* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
 #pragma unroll
     for (int jj = 0; jj < CW; ++jj)
-        if (jj < ncol) store_stream(Pw + (size_t)jj * ld, p[jj]);
+        if (jj < ncol) {
+#pragma unroll
+            for (int nv = 0; nv < NV; ++nv) store_stream(Pw + (size_t)jj * ld + nv * VEC, p[jj][nv]);
+        }
 }
 
 } // namespace nuslam

@@ -403,10 +403,10 @@ int ensure_tick_buffers(nuslam_batch* h)
 {
     if (h->tk_plan) return NUSLAM_OK;
     const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -439,18 +439,27 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
 // The pass over P of one round from the plan and the strips in tk_K / tk_R
 int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan)
 {
-    const int vec = 16 / (int)h->esize();
+    const int vec = 16 / (int)h->esize();                      // rows per lane: 16 bytes' worth
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     const int waves = sweep_waves(h, vec, strips);
     int rc = NUSLAM_OK;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
     const size_t lds = sizeof(double) * ((size_t)J * 2 * 64 * vec + (size_t)waves * J * 5 * kSweepCW);
-    if (waves == 8)
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 8>, grid, block, lds, v, J, plan,
-                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
-    else
-        DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<T, 4>, grid, block, lds, v, J, plan,
-                                       (const double*)h->tk_K, (const double*)h->tk_R, (const T*)h->P(), (T*)h->Palt())));
+    if (h->dtype == NUSLAM_F64) {
+        if (waves == 8)
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+        else
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+    } else {
+        if (waves == 8)
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
+        else
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
+    }
     return rc;
 }
 
