@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--tick-pipeline", action="store_true",
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
+    ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2],
+                    help="nuslam_batch_set_tick_mode: 0 one pass over P per correction, 1 tick pipelines, 2 as 1 but unknown "
+                         "association as one launch per marker instead of the resident round kernel")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
     ap.add_argument("--overlap", action="store_true", help="force the chain of tick t+1 onto a second stream (nuslam_batch_set_overlap; default: on for one filter, off for batches)")
     ap.add_argument("--per-correction", action="store_true",
@@ -322,6 +325,8 @@ def main():
         bt.set_tick_mode(0)
     elif args.tick_pipeline:
         bt.set_tick_mode(1)
+    if args.tick_mode is not None:
+        bt.set_tick_mode(args.tick_mode)
     if args.no_overlap:
         bt.set_overlap(False)
     if args.overlap:
@@ -372,6 +377,8 @@ def main():
     panel_ms, panel_n = bt.profile_read(nh.K_TICK_PANELS)
     apply_ms, apply_n = bt.profile_read(nh.K_TICK_APPLY)
     next_ms, next_n = bt.profile_read(nh.K_TICK_NEXT)
+    dab_ms, dab_n = bt.profile_read(nh.K_DA_BEGIN)
+    das_ms, das_n = bt.profile_read(nh.K_DA_STEP)
     bt.profile(False)
     bad, st = bt.status()
     if st != 0:
@@ -494,9 +501,23 @@ def main():
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
         if apply_n:
-            out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / max(chain_n, 1), "tick_panels": 1e3 * panel_ms / max(panel_n, 1),
+            out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / chain_n if chain_n else None,
+                                     "tick_panels": 1e3 * panel_ms / panel_n if panel_n else None,
                                      "tick_apply": 1e3 * apply_ms / apply_n,
                                      "tick_next": 1e3 * next_ms / next_n if next_n else None})
+            # the pass carries every element through `units` corrections of 7 fp64 FMAs each: besides the bytes it is
+            # bounded by vector fp64 issue (78.6 TFLOP/s), and at 16 corrections per pass that bound is the nearer one
+            fl = 2.0 * 7.0 * L * L * units * B
+            out["roofline"]["fp64_valu"] = {"achieved_TFLOPs": fl / avg_s / 1e12, "peak_TFLOPs": 78.6,
+                                            "frac": fl / avg_s / 1e12 / 78.6,
+                                            "flop_per_launch": fl,
+                                            "note": "7 FMAs per element and correction (sweep_entry), all corrections of the "
+                                                    "tick in one launch; MI355X vector fp64 peak"}
+        if das_n:
+            # unknown association: one resident launch per round of <= 16 markers (k_da_round), or k_da_begin + one
+            # k_da_step per marker when the handle's workgroups do not fit the chip
+            out["kernel_us"].update({"da_round_or_step": 1e3 * das_ms / das_n, "da_launches_per_tick": das_n / max(pred_n, 1),
+                                     "da_begin": 1e3 * dab_ms / dab_n if dab_n else None})
     if args.deferred and flush_n:
         # the covariance pass of this mode is k_flush: once per tick, 2*L^2*w bytes per filter (actual bytes moved)
         per_launch_bytes = 2.0 * L * L * w * B

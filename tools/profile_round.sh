@@ -21,6 +21,8 @@ timeout -k 10 200 $B --per-correction --cpu-seconds 0 > "$OUT/bench_ekf1000_pair
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 > "$OUT/bench_batch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 --trace device > "$OUT/bench_batch_device_trace.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 > "$OUT/bench_da1000.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 2 > "$OUT/bench_da1000_launch_per_marker.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 0 > "$OUT/bench_da1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload ekf5000 > "$OUT/bench_ekf5000.json" 2>> "$OUT/bench.err" || exit 1
 
 stats() {   # name, bench args...
