@@ -281,6 +281,9 @@ def main():
     if B == 1 and args.workload != "batch":
         ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
         bt = ekf.as_batch()
+        if args.per_correction or args.no_pairing or args.group or args.tick_mode == 0:
+            bt.set_tick_mode(0)        # (before the map is initialised: pairing needs the host's mirror of `seen`, which
+                                       # only the per-correction path maintains)
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
         ekf.sync()
         warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and world == 1 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None   # cpu_baseline: N=1 only

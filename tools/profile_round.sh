@@ -18,6 +18,7 @@ step bench lines
 timeout -k 10 300 $B > "$OUT/bench_ekf1000.json" 2> "$OUT/bench_ekf1000.err" || exit 1
 timeout -k 10 200 $B --no-overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_one_stream.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --per-correction --cpu-seconds 0 > "$OUT/bench_ekf1000_pairs.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --no-pairing --cpu-seconds 0 > "$OUT/bench_ekf1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 > "$OUT/bench_batch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 --trace device > "$OUT/bench_batch_device_trace.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 > "$OUT/bench_da1000.json" 2>> "$OUT/bench.err" || exit 1
