@@ -513,9 +513,12 @@ def main():
             fl = 2.0 * 7.0 * L * L * units * B
             out["roofline"]["fp64_valu"] = {"achieved_TFLOPs": fl / avg_s / 1e12, "peak_TFLOPs": 78.6,
                                             "frac": fl / avg_s / 1e12 / 78.6,
+                                            "measured_peak_TFLOPs": 60.7, "frac_of_measured_peak": fl / avg_s / 1e12 / 60.7,
                                             "flop_per_launch": fl,
                                             "note": "7 FMAs per element and correction (sweep_entry), all corrections of the "
-                                                    "tick in one launch; MI355X vector fp64 peak"}
+                                                    "tick in one launch; nominal MI355X vector fp64 peak, and the rate "
+                                                    "tools/micro/fp64_fma_peak.hip measures on this part (the chip holds "
+                                                    "~1.85 GHz under fp64 load)"}
         if das_n:
             # unknown association: one resident launch per round of <= 16 markers (k_da_round), or k_da_begin + one
             # k_da_step per marker when the handle's workgroups do not fit the chip

@@ -797,8 +797,12 @@ __device__ inline void last_term<double>(double& p, double after, double, double
 // that do not depend on J (staging K and R, the tile's loads, its stores -- none of it overlapped with arithmetic,
 // because the eight waves of a CU move in step) plus ~1.4 us per correction (fp64 FMA issue: 224 chain FMAs + ~80 other
 // vector instructions per wave and correction, two waves per SIMD), against 11.4 us of pure FMA issue for J = 16.
-template <typename T, int WAVES, int RPL>
-__global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const TickStep* __restrict__ plan,
+// KLDS = false: the gain rows are not staged in LDS; every lane fetches K_s of its own rows from the strips (L2) two
+// corrections ahead.  The workgroup then holds only its waves' R (10 KB per wave) and nothing is shared between waves: no
+// barrier, three 4-wave workgroups per CU instead of two -- for batches of small filters, where many generations of
+// workgroups pass through a CU and the ones in their load / store phase hide behind the ones doing arithmetic.
+template <typename T, int WAVES, int RPL, bool KLDS>
+__global__ __launch_bounds__(64 * WAVES, KLDS ? 1 : 3) void k_tick_apply(View v, int J, const TickStep* __restrict__ plan,
                                                            const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
                                                            const T* __restrict__ Pin, T* __restrict__ Pout)
 {
@@ -824,22 +828,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
     const TickStep* pl = plan + (size_t)b * kTickJ;
 
     extern __shared__ double lds_apply[];
-    double* Ks = lds_apply;                               // [J][2][ROWS]
-    double* Rs = lds_apply + (size_t)J * 2 * ROWS + (size_t)wave * J * 5 * CW;   // this wave's [J][5][CW]
+    double* Ks = lds_apply;                               // [J][2][ROWS]  (KLDS only)
+    double* Rs = lds_apply + (KLDS ? (size_t)J * 2 * ROWS : 0) + (size_t)wave * J * 5 * CW;   // this wave's [J][5][CW]
 
     // ---- one burst of loads: K (workgroup-cooperative), R (per wave), then the tile
-    constexpr int KCH = kTickJ * 2 * ROWS / 2 / (64 * WAVES);     // 16-byte chunks of K per thread, at most
+    constexpr int KCH = KLDS ? kTickJ * 2 * ROWS / 2 / (64 * WAVES) : 1;     // 16-byte chunks of K per thread, at most
     d2_t kst[KCH];
     const double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
     const int nk = J * 2 * (ROWS / 2);                    // chunks: [J*2 rows][ROWS/2]
+    if (KLDS) {
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-        const int k = threadIdx.x + i * 64 * WAVES;
-        const int kk = k < nk ? k : 0;
-        const int row = kk / (ROWS / 2), piece = kk % (ROWS / 2);
-        int gr = rbase + 2 * piece;
-        gr = gr < ld ? gr : 0;                            // rows past the padded length: any readable address (never used)
-        kst[i] = *reinterpret_cast<const d2_t*>(Kb + (size_t)row * ld + gr);
+        for (int i = 0; i < KCH; ++i) {
+            const int k = threadIdx.x + i * 64 * WAVES;
+            const int kk = k < nk ? k : 0;
+            const int row = kk / (ROWS / 2), piece = kk % (ROWS / 2);
+            int gr = rbase + 2 * piece;
+            gr = gr < ld ? gr : 0;                        // rows past the padded length: any readable address (never used)
+            kst[i] = *reinterpret_cast<const d2_t*>(Kb + (size_t)row * ld + gr);
+        }
     }
     constexpr int RCH = (kTickJ * 5 * CW / 2 + 63) / 64;  // 16-byte chunks of R per lane, at most
     d2_t rst[RCH];
@@ -859,18 +865,33 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
     for (int jj = 0; jj < CW; ++jj)
 #pragma unroll
         for (int nv = 0; nv < NV; ++nv) p[jj][nv] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld + nv * VEC);
+    if (KLDS) {
 #pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-        const int k = threadIdx.x + i * 64 * WAVES;
-        if (k < nk) *reinterpret_cast<d2_t*>(Ks + 2 * (size_t)k) = kst[i];
+        for (int i = 0; i < KCH; ++i) {
+            const int k = threadIdx.x + i * 64 * WAVES;
+            if (k < nk) *reinterpret_cast<d2_t*>(Ks + 2 * (size_t)k) = kst[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < RCH; ++i) {
         const int k = lane + i * 64;
         if (k < nr) *reinterpret_cast<d2_t*>(Rs + 2 * (size_t)k) = rst[i];
     }
-    __syncthreads();
+    if (KLDS) __syncthreads();                            // (without K in LDS a wave reads back only what it wrote itself)
     if (!active) return;
+    // KLDS == false: this lane's gain rows of corrections st and st + 1, fetched two ahead
+    constexpr int KV = RPL / 2;                           // 16-byte pieces per K component
+    const double* Kl0 = Kb + rowc;
+    d2_t kq[2][2][KV];                                    // [which of the two in flight][component][piece]
+    if (!KLDS) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < KV; ++e)
+                    kq[a][r][e] = *reinterpret_cast<const d2_t*>(Kl0 + (size_t)((a < J ? a : 0) * 2 + r) * ld + 2 * e);
+    }
 
     // the step's scalars (skip, c, H) are fetched one correction ahead: a scalar load issued at the top of the
     // iteration that needs it would expose its latency sixteen times
@@ -889,12 +910,23 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
 #pragma unroll
             for (int q = 0; q < 10; ++q) nH[q] = pn->Hc[q];
         }
+        d2_t kc[2][KV];                                   // KLDS == false: K_s of this lane's rows; refill its slot with K_{s+2}
+        if (!KLDS) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < KV; ++e) {
+                    kc[r][e] = kq[0][r][e];
+                    kq[0][r][e] = kq[1][r][e];
+                    kq[1][r][e] = *reinterpret_cast<const d2_t*>(Kl0 + (size_t)((st + 2 < J ? st + 2 : 0) * 2 + r) * ld + 2 * e);
+                }
+        }
         if (skip) continue;                               // wave-uniform
         double m[RPL][5], bef[RPL], aft[RPL];
 #pragma unroll
         for (int e = 0; e < RPL; e += 2) {
-            const d2_t k0 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 0) * ROWS + lane * RPL + e);
-            const d2_t k1 = *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 1) * ROWS + lane * RPL + e);
+            const d2_t k0 = KLDS ? *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 0) * ROWS + lane * RPL + e) : kc[0][e / 2];
+            const d2_t k1 = KLDS ? *reinterpret_cast<const d2_t*>(Ks + (size_t)(st * 2 + 1) * ROWS + lane * RPL + e) : kc[1][e / 2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 const int i = row0 + e + h2;
@@ -960,6 +992,180 @@ __global__ __launch_bounds__(64 * WAVES) void k_tick_apply(View v, int J, const 
 #pragma unroll
             for (int nv = 0; nv < NV; ++nv) store_stream(Pw + (size_t)jj * ld + nv * VEC, p[jj][nv]);
         }
+}
+
+// ------------------------------------------------------------------------------------------------ the pass, one big filter
+// fp64, one resident generation of 8-wave workgroups (a single large filter).  What k_tick_apply left on the table there
+// (phase counters: waves parked 45 % of their life, 34 % of it in the load / store phases, which nothing overlapped
+// because the eight waves of a CU move in step):
+//  * a wave's 16 columns are two UNITS of 8: everything is requested up front, unit A is carried through the J
+//    corrections while unit B's loads are still landing, A's stores drain under B's arithmetic.  For that no vector-memory
+//    result may be waited for inside the loops (vmcnt retires in order: waiting for anything would wait for unit B), so
+//  * the loops read only LDS: M_s(i, set_s) of the workgroup's 128 rows, formed ONCE by the workgroup (wave w forms
+//    corrections w and w + 8) instead of by each of its eight waves, and the unit's prior rows R_s (unit B's travel in
+//    registers until A is done).  LDS: J * (5 * 128 + 8 * 5 * 8) doubles = 120 KB at J = 16.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tick_apply_units(View v, int J, const TickStep* __restrict__ plan,
+                                                                 const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
+                                                                 const double* __restrict__ Pin, double* __restrict__ Pout)
+{
+    typedef Pack16<double> d2_t;
+    constexpr int ROWS = 128, CW = 16, UW = 8;
+    const int b = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ld = v.ld, L = v.L;
+    const int rbase = blockIdx.x * ROWS;
+    const int row0 = rbase + lane * 2;
+    const int strip = blockIdx.y * WAVES + wave;
+    const bool active = strip * CW < L;
+    const int j0 = active ? strip * CW : 0;
+    const bool rows_ok = row0 < ld;
+    const int rowc = rows_ok ? row0 : 0;
+    const int ncol = (L - j0) < CW ? (L - j0) : CW;
+    const TickStep* pl = plan + (size_t)b * kTickJ;
+
+    extern __shared__ double lds_apply[];
+    double* Ms = lds_apply;                                             // [J][5][ROWS]
+    double* Rs = lds_apply + (size_t)J * 5 * ROWS + (size_t)wave * J * 5 * UW;   // this wave's [J][5][UW], one unit at a time
+
+    // ---- everything is requested here
+    constexpr int NP = (kTickJ + WAVES - 1) / WAVES;                    // corrections whose M this wave forms
+    const double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld + rowc;
+    d2_t kk[NP][2];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int st = wave + WAVES * i;
+        const int sq = st < J ? st : 0;
+        kk[i][0] = *reinterpret_cast<const d2_t*>(Kb + (size_t)(sq * 2 + 0) * ld);
+        kk[i][1] = *reinterpret_cast<const d2_t*>(Kb + (size_t)(sq * 2 + 1) * ld);
+    }
+    constexpr int RCH = (kTickJ * 5 * (UW / 2) + 63) / 64;              // 16-byte chunks of one unit's R per lane
+    d2_t ra[RCH], rb[RCH];
+    const double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld + j0;
+    const int nr = J * 5 * (UW / 2);
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+        const int k = lane + i * 64;
+        const int kq = k < nr ? k : 0;
+        const int row = kq / (UW / 2), piece = kq % (UW / 2);
+        ra[i] = *reinterpret_cast<const d2_t*>(Rb + (size_t)row * ld + 2 * piece);
+        rb[i] = *reinterpret_cast<const d2_t*>(Rb + (size_t)row * ld + UW + 2 * piece);
+    }
+    const double* Pr = Pin + (size_t)b * v.p_stride + (size_t)j0 * ld + rowc;
+    d2_t pa[UW], pb[UW];
+#pragma unroll
+    for (int jj = 0; jj < UW; ++jj) pa[jj] = load_stream(Pr + (size_t)(jj < ncol ? jj : 0) * ld);
+#pragma unroll
+    for (int jj = 0; jj < UW; ++jj) pb[jj] = load_stream(Pr + (size_t)(UW + jj < ncol ? UW + jj : 0) * ld);
+
+    // ---- M of corrections wave, wave + WAVES, ... at this lane's two rows: exactly gain_row's M(i, set[q])
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int st = wave + WAVES * i;
+        if (st < J) {
+            const TickStep* ps = pl + st;
+            const int c = ps->c;
+            double Hc[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                d2_t mq;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    double kh = 0.0;
+                    kh = fma(kk[i][0].v[h2], Hc[0 + 2 * q], kh);
+                    kh = fma(kk[i][1].v[h2], Hc[1 + 2 * q], kh);
+                    const int sidx = q < 3 ? q : c + (q - 3);
+                    mq.v[h2] = (row0 + h2 == sidx ? 1.0 : 0.0) - kh;
+                }
+                *reinterpret_cast<d2_t*>(Ms + (size_t)(st * 5 + q) * ROWS + 2 * lane) = mq;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+        const int k = lane + i * 64;
+        if (k < nr) *reinterpret_cast<d2_t*>(Rs + 2 * (size_t)k) = ra[i];
+    }
+    lds_barrier();                                                      // (__syncthreads() would also wait for unit B's loads)
+    if (!active) return;
+
+    auto run_unit = [&](d2_t (&p)[UW]) {
+        int nskip = pl[0].skip, nc = pl[0].c;
+        for (int st = 0; st < J; ++st) {
+            const int skip = nskip, c = nc;
+            {
+                const TickStep* pn = pl + (st + 1 < J ? st + 1 : st);
+                nskip = pn->skip; nc = pn->c;
+            }
+            if (skip) continue;                                         // wave-uniform
+            double m[2][5], bef[2], aft[2];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const d2_t mq = *reinterpret_cast<const d2_t*>(Ms + (size_t)(st * 5 + q) * ROWS + 2 * lane);
+                m[0][q] = mq.v[0]; m[1][q] = mq.v[1];
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int i = row0 + h2;
+                bef[h2] = ((i > 2) && (i < c)) ? 1.0 : 0.0;
+                aft[h2] = (i > c + 1) ? 1.0 : 0.0;
+            }
+            const double* Rst = Rs + (size_t)st * 5 * UW;
+            d2_t rr[5][4];
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rr[q][k] = *reinterpret_cast<const d2_t*>(Rst + q * UW + 2 * k);
+            double acc[8][2];
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[j8][e] = m[e][0] * rr[0][j8 >> 1].v[j8 & 1];
+#pragma unroll
+            for (int q = 1; q < 3; ++q)
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) acc[j8][e] = fma(bef[e], p[j8].v[e], acc[j8][e]);
+#pragma unroll
+            for (int q = 3; q < 5; ++q)
+#pragma unroll
+                for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) acc[j8][e] = fma(m[e][q], rr[q][j8 >> 1].v[j8 & 1], acc[j8][e]);
+#pragma unroll
+            for (int j8 = 0; j8 < 8; ++j8)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) last_term(p[j8].v[e], aft[e], p[j8].v[e], acc[j8][e]);
+        }
+    };
+
+    double* Pw = Pout + (size_t)b * v.p_stride + (size_t)j0 * ld + row0;
+    run_unit(pa);
+    if (rows_ok) {
+#pragma unroll
+        for (int jj = 0; jj < UW; ++jj)
+            if (jj < ncol) store_stream(Pw + (size_t)jj * ld, pa[jj]);
+    }
+    if (ncol <= UW) return;                                             // (the last strip may end inside unit A)
+#pragma unroll
+    for (int i = 0; i < RCH; ++i) {
+        const int k = lane + i * 64;
+        if (k < nr) *reinterpret_cast<d2_t*>(Rs + 2 * (size_t)k) = rb[i];
+    }
+    run_unit(pb);
+    if (rows_ok) {
+#pragma unroll
+        for (int jj = 0; jj < UW; ++jj)
+            if (UW + jj < ncol) store_stream(Pw + (size_t)(UW + jj) * ld, pb[jj]);
+    }
 }
 
 } // namespace nuslam

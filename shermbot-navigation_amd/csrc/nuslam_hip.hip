@@ -91,6 +91,7 @@ struct nuslam_batch {
     // unknown association (ekf_da.h): tracked rows / columns / diagonal blocks of P, one launch per correction
     DaBuf da = {};
     void* da_mem = nullptr;
+    int apply_units = 1;       // fp64, one resident generation: the two-unit pass (k_tick_apply_units); 0: k_tick_apply
     unsigned da_round_tag = 0; // resident round kernel: tags of the key slots, kTickJ + 1 per round (slots are never reset)
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
@@ -403,10 +404,11 @@ int ensure_tick_buffers(nuslam_batch* h)
 {
     if (h->tk_plan) return NUSLAM_OK;
     const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply_units<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 8, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<float, 4, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -437,27 +439,36 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
 }
 
 // The pass over P of one round from the plan and the strips in tk_K / tk_R
-int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan)
+int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, bool shares_chip = false)
 {
     const int vec = 16 / (int)h->esize();                      // rows per lane: 16 bytes' worth
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     const int waves = sweep_waves(h, vec, strips);
     int rc = NUSLAM_OK;
     dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
-    const size_t lds = sizeof(double) * ((size_t)J * 2 * 64 * vec + (size_t)waves * J * 5 * kSweepCW);
+    // one resident generation (waves == 8): the gain rows staged in LDS, shared by the workgroup's waves; many
+    // generations (waves == 4): gain rows from L2, R alone in LDS, three workgroups per CU (see k_tick_apply)
+    const bool k_in_lds = waves == 8 || h->dtype != NUSLAM_F64;
+    const size_t lds = sizeof(double) * ((k_in_lds ? (size_t)J * 2 * 64 * vec : 0) + (size_t)waves * J * 5 * kSweepCW);
     if (h->dtype == NUSLAM_F64) {
-        if (waves == 8)
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+        // (an overlapped run keeps k_tick_apply: its 164 registers leave room for the chain's workgroup on the same SIMDs; beside
+        // the two-unit kernel's 206 the chain had to wait for a CU of its own and the pass took 51 us instead of 40)
+        if (waves == 8 && h->apply_units && !shares_chip)
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply_units<8>, grid, block,
+                            sizeof(double) * (size_t)J * (5 * 128 + 8 * 5 * 8), v, J, plan, (const double*)h->tk_K,
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+        else if (waves == 8)
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
                             (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
         else
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2, false>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
                             (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
     } else {
         if (waves == 8)
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
                             (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
         else
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
+            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
                             (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
     }
     return rc;
@@ -480,7 +491,7 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     if (rc) return rc;
     rc = between();
     if (rc) return rc;
-    return launch_pass(h, v, o.J, plan);
+    return launch_pass(h, v, o.J, plan, compact);
 }
 
 int ensure_da_buffers(nuslam_batch* h)
