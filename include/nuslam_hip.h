@@ -252,7 +252,7 @@ typedef enum {
     NUSLAM_K_TICK_CHAIN = 7,   /* tick pipeline: the serial part of a round of corrections (one workgroup per filter) */
     NUSLAM_K_TICK_PANELS = 8,  /* tick pipeline: the O(len) gain / prior-row strips of the round */
     NUSLAM_K_TICK_APPLY = 9,   /* tick pipeline: the one pass over P that applies the whole round -- the HBM-bound kernel */
-    NUSLAM_K_TICK_NEXT = 10,   /* tick pipeline, overlapped runs: the next tick's starting block from this tick's plan */
+    NUSLAM_K_TICK_NEXT = 10,   /* (no longer launched: the replay of the next tick's starting block is part of NUSLAM_K_TICK_CHAIN) */
     NUSLAM_K_DA_BEGIN = 11,    /* unknown-association tick pipeline: tracked rows / columns / diagonal blocks out of P */
     NUSLAM_K_DA_STEP = 12,     /* ... one correction: association verdict, strips, tracked entries, next marker's candidates */
     NUSLAM_K_COUNT = 13

@@ -62,13 +62,21 @@ struct alignas(16) TickStep {
     double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
 };
 
-// What the chain of the NEXT tick starts from when it runs ahead of the pass over P (nuslam_batch_run on a resident
-// trace): the block and the state at the next tick's index set, after this tick's corrections and the next tick's
-// predict -- formed by k_tick_next from this tick's plan, never read back from the covariance the pass is still writing.
-struct TickHandoff {
-    double BK[kTickNU][kTickNU + 1];
-    double SM[kTickNU + 1];
-    int seen, cached, brk, status;
+// What an overlapped run's chain starts from instead of the covariance (FUSED): the strips of the PREVIOUS tick at this
+// tick's index set, dropped into compact arrays by k_tick_panels, the 35 x 35 block k_tick_prep gathered from the
+// covariance the previous pass reads, that tick's plan and control words, this tick's twist.
+constexpr int kTickCarryLds = ((kTickJ - 7) * 5 * (kTickNU + 1) + kTickJ * 12 + kTickNU + 1) * (int)sizeof(double);
+struct TickCarry {
+    const double* blk;         // [B][NU][NU]   P(U'[p], U'[q]) before the previous tick's corrections
+    const double* KU;          // [B][J][2][NU] K_s at U'
+    const double* RU;          // [B][J][5][NU] R_s at U'
+    const double* SU;          // [B][NU]       state at U' after the previous tick
+    const TickStep* plan_prev; // the previous tick's plan
+    const int* wait_cnt;       // bumped by the kernel behind the previous tick's k_tick_panels
+    int wait_target;
+    int* timeouts;
+    int Jt;                    // markers of the previous tick's round
+    TwistArg tw;               // this tick's twist
 };
 
 // Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
@@ -114,14 +122,180 @@ __global__ __launch_bounds__(64) void k_tick_wait(const int* __restrict__ cnt, i
 {
     if (!tick_wait(cnt, target) && threadIdx.x == 0) atomicAdd(timeouts, 1);
 }
+// ... and the producer side as one: everything the kernels in front of it on its stream stored is published
+__global__ __launch_bounds__(64) void k_tick_signal(int* __restrict__ cnt)
+{
+    if (threadIdx.x == 0) tick_signal(cnt);
+}
+
+// ------------------------------------------------------------------------------------------------ the next tick's start
+// P after the previous tick's corrections and this tick's predict, restricted to this tick's index set U' -- WITHOUT
+// waiting for the pass over P.  Correction s changes entry (a, b) of that 35 x 35 block through K_s(U'[a], :) and
+// R_s(:, U'[b]) only, and those are numbers k_tick_panels produces anyway (it forms K_s for every row and R_s for every
+// column); it drops the ones at U' into compact arrays (a position map says which threads own them), and the block from
+// the covariance the pass will READ (gathered by k_tick_prep) is replayed through the sixteen corrections here, then
+// predict exactly as k_predict writes it (slam_library.cpp:65-148).  Same arithmetic on every entry as the pass itself.
+// Called by all 512 threads of a FUSED chain; U = the index set (already in LDS), FBs = scratch block, out: BKo, SMo and
+// the control words the chain starts from.  (First versions: a 70 x 70 block carried with its own gain rows, 50-60 us on
+// one CU; then this replay as a kernel of its own between the strips and the pass, ~16 us with its launch.)
+template <typename T>
+__device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, const int* U, double (*FBs)[kTickNU + 1],
+                                  double (*BKo)[kTickNU + 1], double* SMo, const int* ctrl4, int& seen, int& cached, int& brk,
+                                  int& status)
+{
+    // 256 threads, and no more LDS than lets the chain's workgroup share a CU with one of the pass (112 KB): the prior
+    // rows R_s at U' of corrections 0..6 live in the scratch block FBs until the replay is over, those of 7..15 and the
+    // plan's scalars in 14.8 KB of dynamic LDS; a thread owns five entries of ONE row of the block and keeps that row's
+    // gains K_s in registers (M_s(U'[a], set_s) is formed from them per correction).
+    constexpr int NU = kTickNU, NT = 256, NE = 5, RS = 5 * (NU + 1);    // entries per thread; doubles per correction of R
+    constexpr int SPLIT = (NU * (NU + 1)) / RS;                         // corrections whose R fits the scratch block: 7
+    static_assert(NU % NE == 0 && (NU / NE) * NU <= NT, "five entries of one row per thread");
+    const int tid = threadIdx.x;
+    const TickStep* pl = cy.plan_prev + (size_t)b * kTickJ;
+    const int Jt = cy.Jt;
+    extern __shared__ double carry_lds[];
+    double* Rhi = carry_lds;                                            // [kTickJ - SPLIT][5][NU + 1]
+    double (*PS)[12] = reinterpret_cast<double (*)[12]>(carry_lds + (kTickJ - SPLIT) * RS);
+    double* SF = carry_lds + (kTickJ - SPLIT) * RS + kTickJ * 12;       // [NU + 1]
+    double* Rlo = &FBs[0][0];
+    __shared__ int canon[NU + 1];
+
+    for (int e = tid; e < kTickJ * 12; e += NT) {
+        const int st = e / 12, f = e % 12;
+        const TickStep* ps = pl + (st < Jt ? st : 0);
+        PS[st][f] = f < 10 ? ps->Hc[f] : (f == 10 ? (double)ps->c : (double)(st < Jt ? ps->skip : 1));
+    }
+    if (tid < NU) {                                                     // the position whose strips stand for this one
+        int cp = tid;
+        for (int k = tid - 1; k >= 0; --k)
+            if (U[k] == U[tid]) cp = k;
+        canon[tid] = cp;
+    }
+    __syncthreads();
+    // the strips at U' (compact, written by k_tick_panels through the position map) and the state there
+    for (int e = tid; e < kTickJ * 5 * NU; e += NT) {
+        const int st = e / (5 * NU), q = (e / NU) % 5, p = e % NU;
+        double* dst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
+        dst[q * (NU + 1) + p] = cy.RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + canon[p]];
+    }
+    if (tid < NU) SF[tid] = cy.SU[(size_t)b * NU + canon[tid]];
+    const bool mine = tid < (NU / NE) * NU;
+    const int a = mine ? tid / (NU / NE) : 0, b0 = mine ? (tid % (NU / NE)) * NE : 0;
+    const int ia = U[a];
+    double K0[kTickJ], K1[kTickJ], E[NE];
+#pragma unroll
+    for (int st = 0; st < kTickJ; ++st) {
+        K0[st] = cy.KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + canon[a]];
+        K1[st] = cy.KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + canon[a]];
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) E[k] = cy.blk[(size_t)b * NU * NU + a * NU + b0 + k];
+    __syncthreads();
+
+#pragma unroll
+    for (int st = 0; st < kTickJ; ++st) {
+        const double* ps = PS[st];
+        if (st < Jt && ps[11] == 0.0) {                                 // (a skipped marker moves nothing in P)
+            const int c = (int)ps[10];
+            double m[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                double kh = 0.0;                                        // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+                kh = fma(K0[st], ps[0 + 2 * q], kh);
+                kh = fma(K1[st], ps[1 + 2 * q], kh);
+                const int sidx = q < 3 ? q : c + (q - 3);
+                m[q] = (ia == sidx ? 1.0 : 0.0) - kh;
+            }
+            const double bef = (ia > 2 && ia < c) ? 1.0 : 0.0, aft = (ia > c + 1) ? 1.0 : 0.0;
+            const double* Rst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                double r[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) r[q] = Rst[q * (NU + 1) + b0 + k];
+                E[k] = p1_entry<T>(m, r, E[k], bef, aft);
+            }
+        }
+    }
+    __syncthreads();                                                    // (the scratch block held R until here)
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < NE; ++k) FBs[a][b0 + k] = E[k];
+    }
+    __syncthreads();
+
+    // ---- this tick's predict on the block and the pose, as k_predict does it (slam_library.cpp:65-148)
+    const double dth = cy.tw.tw ? cy.tw.tw[b * cy.tw.stride + cy.tw.off + 0] : cy.tw.dth0;
+    const double dx = cy.tw.tw ? cy.tw.tw[b * cy.tw.stride + cy.tw.off + 1] : cy.tw.dx0;
+    const double theta = SF[0];
+    double dq_th, dq_x, dq_y;
+    if (dth == 0.0) {
+        dq_th = 0.0;
+        dq_x = dx * cos(theta);
+        dq_y = dx * sin(theta);
+    } else {
+        dq_th = dth;
+        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
+        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
+    }
+    const double th1 = theta + dq_th;
+    double a1, a2;
+    if (dth == 0) {
+        a1 = -dx * sin(th1);
+        a2 = dx * cos(th1);
+    } else {
+        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
+        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
+    }
+    if (tid < NU) {
+        const int p = tid;
+        SMo[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
+    }
+    if (tid == 0) {
+        double pp[3][3], tt[3][3], u[3][3];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) pp[i][j] = FBs[i][j];
+        for (int j = 0; j < 3; ++j) {
+            tt[0][j] = pp[0][j];
+            tt[1][j] = a1 * pp[0][j] + pp[1][j];
+            tt[2][j] = a2 * pp[0][j] + pp[2][j];
+        }
+        for (int i = 0; i < 3; ++i) {
+            u[i][0] = tt[i][0];
+            u[i][1] = tt[i][0] * a1 + tt[i][1];
+            u[i][2] = tt[i][0] * a2 + tt[i][2];
+        }
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) BKo[i][j] = (double)(T)(u[i][j] + v.Q[i + 3 * j]);
+    }
+    for (int e = tid; e < NU * NU; e += NT) {
+        const int p = e / NU, q = e % NU;
+        if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
+        double val = FBs[p][q];
+        if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
+            const double p0 = FBs[0][q];
+            val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
+        } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
+            const double t0 = FBs[p][0];
+            val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
+        }
+        BKo[p][q] = val;
+    }
+    const int* c4 = ctrl4 + 4 * b;
+    seen = c4[0]; cached = c4[0]; brk = 0; status = c4[3];              // slam.cpp:250-251 at this tick's top
+    __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------ the serial chain
 #ifdef NUSLAM_CHAIN_CLOCK
 __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
 #endif
-template <typename T, bool HANDOFF>
+// FUSED: the workgroup first waits for the previous tick's strips, replays that tick's corrections on the 35 x 35 block
+// (what used to be a kernel of its own, k_tick_next: ~5 us of launch and one more hand-off per tick on the critical path
+// of the run) and applies this tick's predict to it (tick_carry), then runs the chain.
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
-                                                    TickStep* __restrict__ plan, const TickHandoff* __restrict__ hin,
+                                                    TickStep* __restrict__ plan, TickCarry cy,
                                                     int* __restrict__ ctrl_out4, int* __restrict__ done_cnt)
 {
     constexpr int NU = kTickNU;
@@ -153,14 +327,21 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     }
     if (tid < 3) Ush[tid] = tid;
     __syncthreads();
-    const TickHandoff* hb = hin + b;
-    for (int e = tid; e < NU * NU; e += 256) {
-        // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
-        // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
-        const int q = e / NU, p = e % NU;
-        BK[0][p][q] = HANDOFF ? hb->BK[p][q] : (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+    int seen = 0, brk = 0, status = 0, cached = 0;
+    if (FUSED) {
+        if (!tick_wait(cy.wait_cnt, cy.wait_target) && tid == 0) atomicAdd(cy.timeouts, 1);
+        tick_carry<T>(v, b, cy, Ush, BK[1], BK[0], SM[0], ctrl_out4, seen, cached, brk, status);
+    } else {
+        for (int e = tid; e < NU * NU; e += 256) {
+            // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
+            // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
+            const int q = e / NU, p = e % NU;
+            BK[0][p][q] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+        }
+        if (tid < NU) SM[0][tid] = s[Ush[tid]];
+        const int* ci = v.c_in + b * C_WORDS;
+        seen = ci[C_SEEN]; brk = ci[C_BRK]; status = ci[C_STATUS]; cached = ci[C_SEEN_CACHED];
     }
-    if (tid < NU) SM[0][tid] = HANDOFF ? hb->SM[tid] : s[Ush[tid]];
     if (wave == 3 && lane < kTickJ) {             // all markers' polar forms at once, one lane each
         double a = 0.0, bb = 0.0;
         if (lane < J) {
@@ -173,9 +354,6 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         zr[lane] = r;
         zphi[lane] = phi;
     }
-    const int* ci = v.c_in + b * C_WORDS;
-    int seen = HANDOFF ? hb->seen : ci[C_SEEN], brk = HANDOFF ? hb->brk : ci[C_BRK], status = HANDOFF ? hb->status : ci[C_STATUS];
-    const int cached = HANDOFF ? hb->cached : ci[C_SEEN_CACHED];
     __syncthreads();
 
     // The block update of correction s is DEFERRED into the first phase of correction s+1, where it runs on waves 0, 2, 3
@@ -399,15 +577,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
     }
 }
 
-// ------------------------------------------------------------------------------------------------ the next tick's start
-// P after this tick's corrections and the next tick's predict, restricted to the next tick's index set U' = U_{t+1} --
-// WITHOUT waiting for the pass over P.  Correction s changes entry (a, b) of that 35 x 35 block through K_s(U'[a], :) and
-// R_s(:, U'[b]) only, and those are numbers k_tick_panels produces anyway (it forms K_s for every row and R_s for every
-// column); it drops the ones at U' into compact arrays (a position map says which threads own them), and k_tick_next
-// replays the sixteen corrections on the block from the covariance the pass will READ (gathered by k_tick_prep), then
-// predict(t+1) exactly as k_predict writes it (slam_library.cpp:65-148).  Same arithmetic on every entry as the pass
-// itself.  (First version: a 70 x 70 block carried with its own gain rows -- 50-60 us on one CU, as long as the chain.)
-
+// ------------------------------------------------------------------------------------------------ overlapped runs: prep
 // behind predict(t) on the handle's stream: the position map of U' (posmap[i] = first position of state index i in U',
 // else -1; the entries set for the previous tick's map -- U_t -- are cleared first) and the block P(U'[p], U'[q]).
 // One more workgroup (blockIdx.x == NU + 1, filter 0) waits for the chain's plan of THIS tick, so that the strips can be
@@ -439,161 +609,6 @@ __global__ __launch_bounds__(64) void k_tick_prep(View v, TickObs ot, TickObs on
     __syncthreads();
     if (p == 0)
         for (int k = NU - 1; k >= 0; --k) pm[index_of(on, k)] = k;      // descending: the FIRST position of an index stays
-}
-
-template <typename T>
-__global__ __launch_bounds__(512) void k_tick_next(View v, TickObs on, TwistArg twn, int Jt, const double* __restrict__ blk,
-                                                   const double* __restrict__ KU, const double* __restrict__ RU,
-                                                   const double* __restrict__ SU, const TickStep* __restrict__ plan,
-                                                   const int* __restrict__ ctrl4, TickHandoff* __restrict__ hout,
-                                                   int* __restrict__ done_cnt)
-{
-    constexpr int NU = kTickNU, NT = 512, NE = (NU * NU + NT - 1) / NT;  // entries per thread
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x;
-    const TickStep* pl = plan + (size_t)b * kTickJ;
-
-    __shared__ double Ml[kTickJ][NU][8];          // M_s(U'[a], set_s[0..4]), before-flag, after-flag: formed once per row
-    __shared__ double RUl[kTickJ][5][NU + 1];
-    __shared__ double PS[kTickJ][12];             // Hc[10], c, skip
-    __shared__ double FB[NU][NU + 1];
-    __shared__ double SF[NU + 1];
-    __shared__ int U[NU + 1], canon[NU + 1];
-
-    if (tid < kTickJ) {
-        int id = 0;
-        if (tid < on.J) id = on.ids ? on.ids[b * on.stride + on.off + tid] : on.id0[tid];
-        const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
-        U[3 + 2 * tid] = c;
-        U[4 + 2 * tid] = c + 1;
-    }
-    if (tid < 3) U[tid] = tid;
-    for (int e = tid; e < kTickJ * 12; e += NT) {
-        const int st = e / 12, f = e % 12;
-        const TickStep* ps = pl + (st < Jt ? st : 0);
-        PS[st][f] = f < 10 ? ps->Hc[f] : (f == 10 ? (double)ps->c : (double)(st < Jt ? ps->skip : 1));
-    }
-    __syncthreads();
-    if (tid < NU) {                                                     // the position whose strips stand for this one
-        int cp = tid;
-        for (int k = tid - 1; k >= 0; --k)
-            if (U[k] == U[tid]) cp = k;
-        canon[tid] = cp;
-    }
-    __syncthreads();
-    // the strips at U' (compact, written by k_tick_panels through the position map) and the state there
-    for (int e = tid; e < kTickJ * NU; e += NT) {
-        const int st = e / NU, p = e % NU;
-        const double* ps = PS[st];
-        const int i = U[p], c = (int)ps[10];
-        const double K0 = KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + canon[p]];
-        const double K1 = KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + canon[p]];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            double kh = 0.0;                                            // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
-            kh = fma(K0, ps[0 + 2 * q], kh);
-            kh = fma(K1, ps[1 + 2 * q], kh);
-            const int sidx = q < 3 ? q : c + (q - 3);
-            Ml[st][p][q] = (i == sidx ? 1.0 : 0.0) - kh;
-        }
-        Ml[st][p][5] = (i > 2 && i < c) ? 1.0 : 0.0;
-        Ml[st][p][6] = (i > c + 1) ? 1.0 : 0.0;
-    }
-    for (int e = tid; e < kTickJ * 5 * NU; e += NT) {
-        const int st = e / (5 * NU), q = (e / NU) % 5, p = e % NU;
-        RUl[st][q][p] = RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + canon[p]];
-    }
-    if (tid < NU) SF[tid] = SU[(size_t)b * NU + canon[tid]];
-    int ea[NE], eb[NE];
-    double E[NE];
-#pragma unroll
-    for (int k = 0; k < NE; ++k) {
-        const int e = tid + NT * k;
-        ea[k] = e < NU * NU ? e / NU : -1;
-        eb[k] = e < NU * NU ? e % NU : 0;
-        E[k] = e < NU * NU ? blk[(size_t)b * NU * NU + e] : 0.0;
-    }
-    __syncthreads();
-
-    for (int st = 0; st < Jt; ++st) {
-        const double* ps = PS[st];
-        if (ps[11] != 0.0) continue;                                    // (a skipped marker moves nothing in P)
-#pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            if (ea[k] < 0) continue;
-            double m[5], r[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { m[q] = Ml[st][ea[k]][q]; r[q] = RUl[st][q][eb[k]]; }
-            E[k] = p1_entry<T>(m, r, E[k], Ml[st][ea[k]][5], Ml[st][ea[k]][6]);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NE; ++k)
-        if (ea[k] >= 0) FB[ea[k]][eb[k]] = E[k];
-    __syncthreads();
-
-    // ---- predict(t+1) on the block and the pose, as k_predict does it (slam_library.cpp:65-148)
-    const double dth = twn.tw ? twn.tw[b * twn.stride + twn.off + 0] : twn.dth0;
-    const double dx = twn.tw ? twn.tw[b * twn.stride + twn.off + 1] : twn.dx0;
-    const double theta = SF[0];
-    double dq_th, dq_x, dq_y;
-    if (dth == 0.0) {
-        dq_th = 0.0;
-        dq_x = dx * cos(theta);
-        dq_y = dx * sin(theta);
-    } else {
-        dq_th = dth;
-        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
-        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
-    }
-    const double th1 = theta + dq_th;
-    double a1, a2;
-    if (dth == 0) {
-        a1 = -dx * sin(th1);
-        a2 = dx * cos(th1);
-    } else {
-        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
-        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
-    }
-    TickHandoff* ho = hout + b;
-    if (tid < NU) {
-        const int p = tid;
-        ho->SM[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
-    }
-    if (tid == 0) {
-        double pp[3][3], tt[3][3], u[3][3];
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) pp[i][j] = FB[i][j];
-        for (int j = 0; j < 3; ++j) {
-            tt[0][j] = pp[0][j];
-            tt[1][j] = a1 * pp[0][j] + pp[1][j];
-            tt[2][j] = a2 * pp[0][j] + pp[2][j];
-        }
-        for (int i = 0; i < 3; ++i) {
-            u[i][0] = tt[i][0];
-            u[i][1] = tt[i][0] * a1 + tt[i][1];
-            u[i][2] = tt[i][0] * a2 + tt[i][2];
-        }
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) ho->BK[i][j] = (double)(T)(u[i][j] + v.Q[i + 3 * j]);
-        const int* c4 = ctrl4 + 4 * b;
-        ho->seen = c4[0]; ho->cached = c4[0]; ho->brk = 0; ho->status = c4[3];     // slam.cpp:250-251 at the next tick's top
-    }
-    for (int e = tid; e < NU * NU; e += NT) {
-        const int p = e / NU, q = e % NU;
-        if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
-        double val = FB[p][q];
-        if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
-            const double p0 = FB[0][q];
-            val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
-        } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
-            const double t0 = FB[p][0];
-            val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
-        }
-        ho->BK[p][q] = val;
-    }
-    __syncthreads();
-    if (tid == 0) tick_signal(done_cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ the panels

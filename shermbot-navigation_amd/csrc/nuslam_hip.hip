@@ -99,7 +99,7 @@ struct nuslam_batch {
     int overlap = -1;          // 1 / 0: nuslam_batch_set_overlap; -1: on for a single filter (96.6 vs 105.5 us per tick at N = 1000),
                                // off for batches, whose pass fills every CU and only delays the chain (6.9M vs 7.2M updates/s)
     hipStream_t stream2 = nullptr;
-    TickStep* tk_plan2 = nullptr; TickHandoff* tk_hand = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
+    TickStep* tk_plan2 = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
     int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
     int* tk_posmap = nullptr; double* tk_KU = nullptr; double* tk_RU = nullptr; double* tk_SU = nullptr;
     int seq_chain = 0, seq_next = 0;                   // the counters' values after everything enqueued so far
@@ -569,7 +569,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         View v = h->view();
         int rc = NUSLAM_OK;
         DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
-                                   (const T*)h->P(), h->tk_plan, (const TickHandoff*)nullptr, (int*)nullptr, (int*)nullptr)));
+                                   (const T*)h->P(), h->tk_plan, TickCarry{}, (int*)nullptr, (int*)nullptr)));
         if (rc) return rc;
         rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, [] { return (int)NUSLAM_OK; });
         if (rc) return rc;
@@ -676,7 +676,8 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * B * kTickJ));
-        HIPCHK(hipMalloc(&h->tk_hand, sizeof(TickHandoff) * B));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * B));
         HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * B * kTickNU * kTickNU));
         HIPCHK(hipMalloc(&h->tk_posmap, sizeof(int) * B * h->ld));
@@ -708,6 +709,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
     int* cnt_next = h->tk_sync + 1;
     int* timeouts = h->tk_sync + 2;
     int rc = NUSLAM_OK;
+    int prev_J = 0;
     for (int t = t_begin; t < t_end; ++t) {
         TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
         const bool more = t + 1 < t_end;
@@ -724,13 +726,19 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             HIPCHK(hipEventRecord(h->ov_start, h->stream));               // once per run
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_start, 0));
             DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
-                                          total, (const T*)h->P(), plan, (const TickHandoff*)nullptr, h->tk_ctrl4, cnt_chain)));
+                                          total, (const T*)h->P(), plan, TickCarry{}, h->tk_ctrl4, cnt_chain)));
         } else {
-            rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts);
-            if (rc) return rc;
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256), 0, v, o,
-                                          total, (const T*)h->P(), plan, (const TickHandoff*)h->tk_hand, h->tk_ctrl4, cnt_chain)));
+            // (it waits, inside, for the strips of tick t-1 at this tick's index set: cnt_next counts the signal kernels
+            // enqueued behind k_tick_panels)
+            TickCarry cy;
+            cy.blk = h->tk_blk; cy.KU = h->tk_KU; cy.RU = h->tk_RU; cy.SU = h->tk_SU;
+            cy.plan_prev = ((t - t_begin) & 1) ? h->tk_plan : h->tk_plan2;
+            cy.wait_cnt = cnt_next; cy.wait_target = h->seq_next; cy.timeouts = timeouts;
+            cy.Jt = prev_J; cy.tw = twist_of(t);
+            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256),
+                                          (size_t)kTickCarryLds, v, o, total, (const T*)h->P(), plan, cy, h->tk_ctrl4, cnt_chain)));
         }
+        prev_J = o.J;
         if (rc) return rc;
         h->seq_chain += h->B;
         // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), next(t), the pass over P
@@ -742,13 +750,8 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         if (rc) return rc;
         rc = launch_strips_and_pass(h, v, o, plan, more, [&]() -> int {
             if (!more) return NUSLAM_OK;
-            int r2 = NUSLAM_OK;
-            DISPATCH_T(h, r2 = (launch(h, NUSLAM_K_TICK_NEXT, k_tick_next<T>, dim3(h->B), dim3(512), v, obs_of(t + 1), twist_of(t + 1),
-                                       o.J, (const double*)h->tk_blk, (const double*)h->tk_KU, (const double*)h->tk_RU,
-                                       (const double*)h->tk_SU, (const TickStep*)plan, (const int*)h->tk_ctrl4, h->tk_hand,
-                                       cnt_next)));
-            h->seq_next += h->B;
-            return r2;
+            h->seq_next += 1;                       // the strips at the next tick's index set are complete: chain(t+1) may start
+            return launch(h, -1, k_tick_signal, dim3(1), dim3(64), cnt_next);
         });
         if (rc) return rc;
         h->sidx ^= 1;
@@ -766,7 +769,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_hand, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
