@@ -663,6 +663,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
 
             // ---- loads that depend on the landmark
             double g0 = 0.0, g1 = 0.0;
+            double val = 0.0;                              // wave 2: one tracked entry / state entry / packet entry per lane
             double th_old = 0.0, kp0 = 0.0, kp1 = 0.0;     // wave 2: the heading before, K_s(0, :)
             if (wave == 0) {
                 g0 = (double)Pb[(size_t)tr_ * ld + c];
@@ -682,7 +683,81 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 const int sl = lane - 32;
                 if (sl >= 0 && sl < 5) src = sc + setv[sl];
                 if (matched && sl >= 8 && sl < 24) src = d.AP[par] + ((size_t)b * n + (c - 3) / 2) * 16 + (sl - 8);
-                const double val = ld_agent(src);
+                val = ld_agent(src);
+            } else {
+                // lanes (t', e): the coefficients of rows / columns c + e through correction t'
+                const int tp = lane >> 1, e = lane & 1;
+                if (lane < 2 * kTickJ && tp < st && !dd.skip) {
+                    const int cp = (int)hist[tp][10];
+                    const int i = c + e;
+                    const double K0 = ld_agent(&Kb[(size_t)(tp * 2 + 0) * ld + i]), K1 = ld_agent(&Kb[(size_t)(tp * 2 + 1) * ld + i]);
+                    double rr[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) rr[q] = ld_agent(&Rb[(size_t)(tp * 5 + q) * ld + i]);
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        double kh = 0.0;
+                        kh = fma(K0, hist[tp][0 + 2 * q], kh);
+                        kh = fma(K1, hist[tp][1 + 2 * q], kh);
+                        const int sidx = q < 3 ? q : cp + (q - 3);
+                        mcL[tp][e][q] = (i == sidx ? 1.0 : 0.0) - kh;
+                        rcL[tp][e][q] = rr[q];
+                    }
+                    mcL[tp][e][5] = (i > 2 && i < cp) ? 1.0 : 0.0;
+                    mcL[tp][e][6] = (i > cp + 1) ? 1.0 : 0.0;
+                }
+            }
+            // ---- the replay coefficients are in LDS: the replay (waves 0, 1) runs beside the head (wave 2), whose loads
+            // are still in flight (an LDS-only barrier: nobody waits for vector memory here)
+            lds_barrier();
+            if (wave == 0 && !dd.skip) {
+                // rows c, c+1 of P_{s-1} at column t: the gathered entries replayed through corrections 0..s-1, two
+                // corrections per trip so that the second one's coefficients are on their way from LDS while the first
+                // is applied (a register-rotating prefetch cost more in moves than it hid)
+                unsigned todo = live;
+                while (todo) {
+                    const int ta = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const bool two = todo != 0;
+                    const int tb = two ? __builtin_ctz(todo) : ta;
+                    if (two) todo &= todo - 1;
+                    double ra[5], rb[5], ma[7], mb[7], na[7], nb[7];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { ra[q] = Rl[(ta * 5 + q) * kDaSlots + lane]; rb[q] = Rl[(tb * 5 + q) * kDaSlots + lane]; }
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) { ma[q] = mcL[ta][0][q]; mb[q] = mcL[ta][1][q]; na[q] = mcL[tb][0][q]; nb[q] = mcL[tb][1][q]; }
+                    g0 = p1_entry<T>(ma, ra, g0, ma[5], ma[6]);
+                    g1 = p1_entry<T>(mb, ra, g1, mb[5], mb[6]);
+                    if (two) {
+                        g0 = p1_entry<T>(na, rb, g0, na[5], na[6]);
+                        g1 = p1_entry<T>(nb, rb, g1, nb[5], nb[6]);
+                    }
+                }
+            } else if (wave == 1 && !dd.skip) {
+                unsigned todo = live;
+                while (todo) {
+                    const int ta = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const bool two = todo != 0;
+                    const int tb = two ? __builtin_ctz(todo) : ta;
+                    if (two) todo &= todo - 1;
+                    double mta[5], mtb[5], ra0[5], ra1[5], rb0[5], rb1[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        mta[q] = Ml[(ta * 5 + q) * kDaSlots + lane]; mtb[q] = Ml[(tb * 5 + q) * kDaSlots + lane];
+                        ra0[q] = rcL[ta][0][q]; ra1[q] = rcL[ta][1][q]; rb0[q] = rcL[tb][0][q]; rb1[q] = rcL[tb][1][q];
+                    }
+                    const int cpa = (int)hist[ta][10], cpb = (int)hist[tb][10];
+                    const double bpa = (t > 2 && t < cpa) ? 1.0 : 0.0, apa = (t > cpa + 1) ? 1.0 : 0.0;
+                    const double bpb = (t > 2 && t < cpb) ? 1.0 : 0.0, apb = (t > cpb + 1) ? 1.0 : 0.0;
+                    g0 = p1_entry<T>(mta, ra0, g0, bpa, apa);
+                    g1 = p1_entry<T>(mta, ra1, g1, bpa, apa);
+                    if (two) {
+                        g0 = p1_entry<T>(mtb, rb0, g0, bpb, apb);
+                        g1 = p1_entry<T>(mtb, rb1, g1, bpb, apb);
+                    }
+                }
+            } else if (wave == 2) {
                 const double th = lane_bcast(val, 32), x = lane_bcast(val, 33), y = lane_bcast(val, 34);
                 double lx = lane_bcast(val, 35), ly = lane_bcast(val, 36);
                 const double r = Zl[0][st], phi = Zl[1][st];
@@ -737,28 +812,6 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     hd[14] = lx; hd[15] = ly; hd[16] = dz0; hd[17] = dz1;
                     hi[0] = skip0 ? 1 : 0; hi[1] = stt;
                 }
-            } else {
-                // lanes (t', e): the coefficients of rows / columns c + e through correction t'
-                const int tp = lane >> 1, e = lane & 1;
-                if (lane < 2 * kTickJ && tp < st && !dd.skip) {
-                    const int cp = (int)hist[tp][10];
-                    const int i = c + e;
-                    const double K0 = ld_agent(&Kb[(size_t)(tp * 2 + 0) * ld + i]), K1 = ld_agent(&Kb[(size_t)(tp * 2 + 1) * ld + i]);
-                    double rr[5];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) rr[q] = ld_agent(&Rb[(size_t)(tp * 5 + q) * ld + i]);
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) {
-                        double kh = 0.0;
-                        kh = fma(K0, hist[tp][0 + 2 * q], kh);
-                        kh = fma(K1, hist[tp][1 + 2 * q], kh);
-                        const int sidx = q < 3 ? q : cp + (q - 3);
-                        mcL[tp][e][q] = (i == sidx ? 1.0 : 0.0) - kh;
-                        rcL[tp][e][q] = rr[q];
-                    }
-                    mcL[tp][e][5] = (i > 2 && i < cp) ? 1.0 : 0.0;
-                    mcL[tp][e][6] = (i > cp + 1) ? 1.0 : 0.0;
-                }
             }
             DCK(2);
             __syncthreads();
@@ -776,28 +829,6 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
 
             if (wave == 0) {
                 if (!nocorr) {
-                    // rows c, c+1 of P_{s-1} at column t: the gathered entries replayed through corrections 0..s-1, two
-                    // corrections per trip so that the second one's coefficients are on their way from LDS while the first
-                    // is applied (a register-rotating prefetch cost more in moves than it hid)
-                    unsigned todo = live;
-                    while (todo) {
-                        const int ta = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        const bool two = todo != 0;
-                        const int tb = two ? __builtin_ctz(todo) : ta;
-                        if (two) todo &= todo - 1;
-                        double ra[5], rb[5], ma[7], mb[7], na[7], nb[7];
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) { ra[q] = Rl[(ta * 5 + q) * kDaSlots + lane]; rb[q] = Rl[(tb * 5 + q) * kDaSlots + lane]; }
-#pragma unroll
-                        for (int q = 0; q < 7; ++q) { ma[q] = mcL[ta][0][q]; mb[q] = mcL[ta][1][q]; na[q] = mcL[tb][0][q]; nb[q] = mcL[tb][1][q]; }
-                        g0 = p1_entry<T>(ma, ra, g0, ma[5], ma[6]);
-                        g1 = p1_entry<T>(mb, ra, g1, mb[5], mb[6]);
-                        if (two) {
-                            g0 = p1_entry<T>(na, rb, g0, na[5], na[6]);
-                            g1 = p1_entry<T>(nb, rb, g1, nb[5], nb[6]);
-                        }
-                    }
                     const double rs[5] = { e3[0], e3[1], e3[2], g0, g1 };
 #pragma unroll
                     for (int q = 0; q < 5; ++q) {
@@ -819,29 +850,6 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     if (t == c + 1) snew = ly;
                 }
                 if (!nocorr) {
-                    unsigned todo = live;
-                    while (todo) {
-                        const int ta = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        const bool two = todo != 0;
-                        const int tb = two ? __builtin_ctz(todo) : ta;
-                        if (two) todo &= todo - 1;
-                        double mta[5], mtb[5], ra0[5], ra1[5], rb0[5], rb1[5];
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            mta[q] = Ml[(ta * 5 + q) * kDaSlots + lane]; mtb[q] = Ml[(tb * 5 + q) * kDaSlots + lane];
-                            ra0[q] = rcL[ta][0][q]; ra1[q] = rcL[ta][1][q]; rb0[q] = rcL[tb][0][q]; rb1[q] = rcL[tb][1][q];
-                        }
-                        const int cpa = (int)hist[ta][10], cpb = (int)hist[tb][10];
-                        const double bpa = (t > 2 && t < cpa) ? 1.0 : 0.0, apa = (t > cpa + 1) ? 1.0 : 0.0;
-                        const double bpb = (t > 2 && t < cpb) ? 1.0 : 0.0, apb = (t > cpb + 1) ? 1.0 : 0.0;
-                        g0 = p1_entry<T>(mta, ra0, g0, bpa, apa);
-                        g1 = p1_entry<T>(mta, ra1, g1, bpa, apa);
-                        if (two) {
-                            g0 = p1_entry<T>(mtb, rb0, g0, bpb, apb);
-                            g1 = p1_entry<T>(mtb, rb1, g1, bpb, apb);
-                        }
-                    }
                     const double pc[5] = { e3[0], e3[1], e3[2], g0, g1 };
                     double K[2];
                     gain_row(pc, Hc, Si, t, setv, K, m5);
