@@ -735,6 +735,12 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             cy.plan_prev = ((t - t_begin) & 1) ? h->tk_plan : h->tk_plan2;
             cy.wait_cnt = cnt_next; cy.wait_target = h->seq_next; cy.timeouts = timeouts;
             cy.Jt = prev_J; cy.tw = twist_of(t);
+            // Many filters: their chains' workgroups must not sit on the CUs spinning while the strips they wait for still
+            // need room to run -- a one-wave kernel does the waiting for them (their own wait then falls through).
+            if ((long long)h->B * 4 > h->n_cu) {
+                rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts);
+                if (rc) return rc;
+            }
             DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256),
                                           (size_t)kTickCarryLds, v, o, total, (const T*)h->P(), plan, cy, h->tk_ctrl4, cnt_chain)));
         }

@@ -115,7 +115,8 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
     assert es < 1e-6 and ep < 1e-6
 
 
-@pytest.mark.parametrize("B,n,m,dtype,cold", [(1, 40, 16, 0, False), (3, 30, 5, 0, False), (4, 20, 16, 1, False), (2, 12, 8, 0, True)])
+@pytest.mark.parametrize("B,n,m,dtype,cold", [(1, 40, 16, 0, False), (3, 30, 5, 0, False), (4, 20, 16, 1, False), (2, 12, 8, 0, True),
+                                                (96, 10, 6, 0, True)])     # (more chains than a quarter of the CUs: a one-wave kernel waits for them)
 def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold):
     """nuslam_batch_run with the chain of tick t+1 running ahead on its own stream (k_tick_next forms its starting block
     from tick t's plan) against the one-stream order: same state, covariance, seen, status -- warm, through first
