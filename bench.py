@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2],
                     help="nuslam_batch_set_tick_mode: 0 one pass over P per correction, 1 tick pipelines, 2 as 1 but unknown "
                          "association as one launch per marker instead of the resident round kernel")
+    ap.add_argument("--plain-pass", action="store_true", help="nuslam_batch_set_pass_variant(1): k_tick_apply also where the "
+                    "two-unit kernel would run (to count the default run's kernel in a serialised --pmc pass)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
     ap.add_argument("--overlap", action="store_true", help="force the chain of tick t+1 onto a second stream (nuslam_batch_set_overlap; default: on for one filter, off for batches)")
     ap.add_argument("--per-correction", action="store_true",
@@ -330,6 +332,8 @@ def main():
         bt.set_tick_mode(1)
     if args.tick_mode is not None:
         bt.set_tick_mode(args.tick_mode)
+    if args.plain_pass:
+        bt.set_pass_variant(1)
     if args.no_overlap:
         bt.set_overlap(False)
     if args.overlap:
@@ -475,6 +479,11 @@ def main():
     if apply_n:
         # the tick pipeline: ONE pass over P applies all m corrections of the tick
         sweep_ms, sweep_n, sweep_kernel, units = apply_ms, apply_n, "k_tick_apply", m
+        # which instantiation of the pass ran (csrc/nuslam_hip.hip::launch_pass): one big fp64 filter with the chip to
+        # itself -> the two-unit kernel; overlapped with the next tick's chain, batches, fp32 -> k_tick_apply
+        overlapped = known and B == 1 and not args.no_overlap and args.workload == "ekf1000" and args.tick_mode != 0
+        if dtype == nh.F64 and B == 1 and L >= 1000 and not overlapped and not args.plain_pass:
+            sweep_kernel = "k_tick_apply_units"
     elif pair_n > sweep_n:
         # most corrections went through k_update2: TWO corrections per pass over P (bit-identical to two k_update)
         sweep_ms, sweep_n, sweep_kernel, units = pair_ms, pair_n, "k_update2", 2
@@ -488,7 +497,7 @@ def main():
         avg_s = 1e-3 * sweep_ms / sweep_n
         ach = min_bytes / avg_s / 1e9
         tname = "double" if dtype == nh.F64 else "float"
-        traffic, traffic_src = pmc_traffic(nh, "%s<%s" % (sweep_kernel, tname))
+        traffic, traffic_src = pmc_traffic(nh, "k_tick_apply_units<" if sweep_kernel == "k_tick_apply_units" else "%s<%s" % (sweep_kernel, tname))
         out["roofline"] = {"bound": "hbm", "kernel": sweep_kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": 1e6 * avg_s, "launches": sweep_n, "corrections_per_launch": units,

@@ -190,6 +190,10 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
  * markers from the resident trace; the streams hand over through device counters, every wait bounded).  Same bits
  * either way.  enable < 0 (default): on for a handle of one filter, off for batches (measured). */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
+/* Which instantiation of the pass over the covariance a tick pipeline uses for one large fp64 filter: 0 (default) = the
+ * two-unit kernel when the pass has the chip to itself, the plain one beside the chain of an overlapped run; 1 = always
+ * the plain one (profiling: counter passes serialise the dispatches, so an overlapped run cannot be counted).  Same bits. */
+int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */
 /* The simulator's loop, nuturtlesim/src/tube_world.cpp:509-533, run on the device for every filter of a batch and

@@ -1014,6 +1014,7 @@ const char* nuslam_strerror(int status)
     case NUSLAM_E_NOMEM: return "out of memory";
     case NUSLAM_E_CAPACITY: return "a fixed-size device table is too small for this input";
     case NUSLAM_E_COMM: return "RCCL error; nuslam_last_hip_error() has the text";
+    case NUSLAM_E_SYNC: return "a bounded device-side wait expired (overlapped run / resident round): results invalid";
     default: return "unknown status";
     }
 }
@@ -1414,6 +1415,13 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
     if (!h || mode < -1 || mode > 2) return NUSLAM_E_ARG;
     h->tick_mode = mode;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
+{
+    if (!h || variant < 0 || variant > 1) return NUSLAM_E_ARG;
+    h->apply_units = variant == 0;
     return NUSLAM_OK;
 }
 

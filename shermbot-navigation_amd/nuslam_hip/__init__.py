@@ -67,6 +67,7 @@ SYMBOLS = [
     ("nuslam_batch_set_pairing", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_tick_mode", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_overlap", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_set_pass_variant", C.c_int, [_vp, C.c_int]),
     ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
@@ -395,6 +396,9 @@ class Batch:
 
     def set_overlap(self, enable=True):
         _chk(lib().nuslam_batch_set_overlap(self._h, -1 if enable is None else (1 if enable else 0)), "batch_set_overlap")
+
+    def set_pass_variant(self, variant):
+        _chk(lib().nuslam_batch_set_pass_variant(self._h, int(variant)), "batch_set_pass_variant")
 
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")

@@ -54,7 +54,13 @@ PM="--steps 40 --warmup 10 --blocks 1 --cpu-seconds 0"
 # (counter passes serialise the dispatches, so they run the one-stream order: the kernel and its bytes are the same)
 pmc ekf1000 FETCH_SIZE $PM --no-overlap || exit 1
 pmc ekf1000 WRITE_SIZE $PM --no-overlap || exit 1
-python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_pmc_hbm_traffic.json" \
+python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_one_stream_pmc_hbm_traffic.json" \
+    "k_tick_apply_units<" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
+# the default (overlapped) run's pass, k_tick_apply<double, 8, 2, true>: counter passes serialise the dispatches, under which
+# the chain of an overlapped run never meets its strips (the waits expire, NUSLAM_E_SYNC) -- so the same kernel is counted
+# in a one-stream run that selects it (--plain-pass)
+pmc ekf1000ov FETCH_SIZE $PM --no-overlap --plain-pass && pmc ekf1000ov WRITE_SIZE $PM --no-overlap --plain-pass && \
+python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000ov_FETCH_SIZE" "$OUT/pmc_ekf1000ov_WRITE_SIZE" "$OUT/ekf1000_pmc_hbm_traffic.json" \
     "k_tick_apply<double" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
 PB="--workload batch --steps 6 --warmup 2 --blocks 1 --cpu-seconds 0"
 pmc batch FETCH_SIZE $PB || exit 1
