@@ -187,10 +187,11 @@ def cpu_baseline(n, m, tr, budget_s, warm_state):
             "ms_per_step": 1e3 * dt / done}, o, cands["oracle-c"][1]
 
 
-def pmc_traffic(nh, sweep_kernel_sig):
+def pmc_traffic(nh, sweep_kernel_sig, min_bytes):
     """HBM bytes per launch from a committed rocprofv3 --pmc measurement (profiles/r*/**pmc_hbm*.json made by
     tools/summarize_pmc.py), quoted ONLY when that record was taken from the very kernel sources the loaded library
-    was built from (nuslam_build_info) and names the kernel instantiation this run's launches used; otherwise null."""
+    was built from (nuslam_build_info), names the kernel this run's launches used and was taken at this run's size (same
+    minimum bytes per launch); otherwise null."""
     import glob
     have = nh.build_info()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_hbm*.json")), reverse=True):
@@ -198,7 +199,8 @@ def pmc_traffic(nh, sweep_kernel_sig):
             rec = json.load(open(f))
         except Exception:
             continue
-        if rec.get("build_info") == have and sweep_kernel_sig in rec.get("kernel_name", ""):
+        if (rec.get("build_info") == have and sweep_kernel_sig in rec.get("kernel_name", "")
+                and abs(rec.get("per_launch_bytes", {}).get("min_bytes", -1) - min_bytes) < 1):
             return rec["per_launch_bytes"]["hbm_traffic"], os.path.relpath(f, ROOT)
     return None, None
 
@@ -497,7 +499,7 @@ def main():
         avg_s = 1e-3 * sweep_ms / sweep_n
         ach = min_bytes / avg_s / 1e9
         tname = "double" if dtype == nh.F64 else "float"
-        traffic, traffic_src = pmc_traffic(nh, "k_tick_apply_units<" if sweep_kernel == "k_tick_apply_units" else "%s<%s" % (sweep_kernel, tname))
+        traffic, traffic_src = pmc_traffic(nh, "k_tick_apply_units<" if sweep_kernel == "k_tick_apply_units" else "%s<%s" % (sweep_kernel, tname), min_bytes)
         out["roofline"] = {"bound": "hbm", "kernel": sweep_kernel, "achieved": ach, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_us": 1e6 * avg_s, "launches": sweep_n, "corrections_per_launch": units,

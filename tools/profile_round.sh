@@ -26,6 +26,10 @@ timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 2 > "
 timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 0 > "$OUT/bench_da1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload ekf5000 > "$OUT/bench_ekf5000.json" 2>> "$OUT/bench.err" || exit 1
 
+# second pass (ONLY_BENCH=1): the bench lines again, now that profiles/<round>/ holds counter records of this build, so that
+# their `roofline.traffic` is filled in
+[ "${ONLY_BENCH:-0}" = "1" ] && { step "done (bench lines only)"; exit 0; }
+
 stats() {   # name, bench args...
     local name=$1; shift
     step "rocprofv3 --kernel-trace --stats: $name"
