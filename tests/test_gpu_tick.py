@@ -116,10 +116,11 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
 
 
 @pytest.mark.parametrize("B,n,m,dtype,cold", [(1, 40, 16, 0, False), (3, 30, 5, 0, False), (4, 20, 16, 1, False), (2, 12, 8, 0, True),
-                                                (96, 10, 6, 0, True)])     # (more chains than a quarter of the CUs: a one-wave kernel waits for them)
+                                                (96, 10, 6, 0, True),      # (more chains than a quarter of the CUs: a one-wave kernel waits for them)
+                                                (1, 1000, 16, 0, False)])  # BASELINE configs[1] size: the bench's default path
 def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold):
-    """nuslam_batch_run with the chain of tick t+1 running ahead on its own stream (k_tick_next forms its starting block
-    from tick t's plan) against the one-stream order: same state, covariance, seen, status -- warm, through first
+    """nuslam_batch_run with the chain of tick t+1 running ahead on its own stream (it forms its starting block from
+    tick t's strips itself: tick_carry) against the one-stream order: same state, covariance, seen, status -- warm, through first
     sightings (cold), with skipped markers and a straight tick (dth == 0) in the trace, fp64 and fp32 storage."""
     T = 7
     traces = [synth.make_trace(n, T, m, seed=400 + k, straight_every=3) for k in range(B)]
