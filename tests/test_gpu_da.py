@@ -171,3 +171,26 @@ def test_da_pipeline_n1000(hip, pipe):
         assert a.seen == b.seen and np.array_equal(a.state, b.state), "tick %d" % t
     assert ia is not None and np.array_equal(a.cov, b.cov)
     assert a.seen == 999
+
+
+def test_da_pipeline_long_run_n1000(hip):
+    """1500 ticks x 16 markers at N = 1000 through nuslam_batch_run: the resident round kernel (24 000 meets of 34
+    workgroups), the launch-per-marker variant and the per-correction kernels end in the same bits, no wait expires."""
+    n, n_world, m, T = 1000, 998, 16, 1500
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    lm = synth.make_landmarks(n_world)
+    tr = synth.make_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
+    res = []
+    for mode in (1, 2, 0):
+        ekf = hip.EKF(np.zeros(3), np.zeros(2 * n), Qs, R)
+        ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+        bt = ekf.as_batch()
+        bt.set_tick_mode(mode)
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, None, bcast=True)
+        for t0 in range(0, T, 500):
+            bt.run(t0, t0 + 500)
+        assert bt.status() == (-1, 0)
+        res.append((ekf.state, ekf.cov, ekf.seen))
+    for r in res[1:]:
+        assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1]) and res[0][2] == r[2]
