@@ -41,7 +41,7 @@ template <> struct Mfma<double> {
 
 template <typename T> struct alignas(16) V16 { T v[16 / sizeof(T)]; };
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BK = 16;
 
 // C(i,j) = sum_k A(i,k) * Bop(k,j) [+ Q(i,j) on the 3x3 corner]
 //   A   : (i,k) at A[i + k*ld]                         (contiguous along i)
@@ -52,15 +52,23 @@ constexpr int BM = 128, BN = 128, BK = 16;
 // flight into registers and are written to stage (t+1)&1 after the compute -- one barrier per K-tile.
 // Workgroup order: the linear id is remapped so that the workgroups dealt to one XCD (ids congruent mod 8) cover a
 // contiguous band of block rows and share their B strips in that XCD's L2.
-template <typename T, bool B_KMAJOR, bool ADD_Q>
-__global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict__ A, const T* __restrict__ B,
+//
+// TILE = 128 (a wave owns 64 x 64) or 64 (32 x 32).  The grid is one-dimensional: this launch covers the 128 x 128 tiles
+// tile0 .. tile0 + n - 1 of the gx-wide tile grid, as n workgroups (TILE = 128) or 4 n (TILE = 64, four quadrants per
+// tile).  The small tiles exist for the TAIL: 6241 tiles on 768 resident workgroups leave a ninth generation that is one
+// eighth full -- a whole tile time with most CUs idle (10 % of the product).  Those last tiles are launched as quadrants
+// instead: four times the workgroups, a quarter of the time each, the same sum for every element (k ascending), so the
+// result does not change by a bit.
+template <typename T, bool B_KMAJOR, bool ADD_Q, int TILE>
+__global__ __launch_bounds__(256) void k_gemm(int L, int ld, int gx, int tile0, const T* __restrict__ A, const T* __restrict__ B,
                                               T* __restrict__ C, double q00, double q10, double q20, double q01,
                                               double q11, double q21, double q02, double q12, double q22)
 {
     typedef Mfma<T> M;
     typedef typename M::acc_t acc_t;
+    constexpr int BM = TILE, BN = TILE;
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int NT = 64 / M::TM;            // MFMA tiles per wave edge
+    constexpr int NT = (TILE / 2) / M::TM;    // MFMA tiles per wave edge
     constexpr int PB = B_KMAJOR ? 1 : 0;      // odd row stride -> conflict-free transposing stores
     constexpr int AV = BM / VEC;              // 16-byte vectors per k-row of the A tile
     constexpr int NA = (BK * AV) / 256;       // vectors per thread, A tile
@@ -73,13 +81,15 @@ __global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int it = (wave & 1) * 64, jt = (wave >> 1) * 64;
-    // XCD-aware tile order (bijective for any grid size)
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int orig = blockIdx.y * gx + blockIdx.x;
+    const int it = (wave & 1) * (TILE / 2), jt = (wave >> 1) * (TILE / 2);
+    // XCD-aware order (bijective for any grid size)
+    const int nwg = gridDim.x;
+    const int orig = blockIdx.x;
     const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int i0 = (wg % gx) * BM, j0 = (wg / gx) * BN;
+    constexpr int SUB = 128 / TILE;           // quadrants per tile edge
+    const int tile = tile0 + wg / (SUB * SUB), quad = wg % (SUB * SUB);
+    const int i0 = (tile % gx) * 128 + (quad % SUB) * TILE, j0 = (tile / gx) * 128 + (quad / SUB) * TILE;
     const int idx = M::idx(lane), kk = M::kk(lane);
 
     acc_t acc[NT][NT];
@@ -178,14 +188,34 @@ __global__ __launch_bounds__(256) void k_gemm(int L, int ld, const T* __restrict
 template <typename T>
 int run_t(int L, int ld, const T* F, T* P, T* Tw, const double Q[9], hipStream_t stream, hipEvent_t ev[4])
 {
-    dim3 grid((L + BM - 1) / BM, (L + BN - 1) / BN), block(256);
+    const int gx = (L + 127) / 128, ntiles = gx * gx;
+    // the tail (see k_gemm): what is left over after whole generations of resident workgroups, if that is less than half
+    // a generation, goes out as quadrants behind the big tiles
+    static int n_cu = 0;                                                 // (one device type per process)
+    if (!n_cu) {
+        int dev = 0, cus = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+    }
+    const int gen = n_cu * (sizeof(T) == 4 ? 3 : 1);                    // resident workgroups: 3 per CU (f32), 1 (f64: 65 KB of LDS, 206 + 128 registers)
+    int tail = ntiles % gen;
+    if (tail * 2 > gen || ntiles < gen) tail = 0;
+    const int big = ntiles - tail;
+    dim3 block(256);
     // T = F * P            (slam_library.cpp:104, left product first)
-    hipExtLaunchKernelGGL((k_gemm<T, true, false>), grid, block, 0, stream, ev ? ev[0] : nullptr, ev ? ev[1] : nullptr, 0,
-                          L, ld, F, (const T*)P, Tw, 0., 0., 0., 0., 0., 0., 0., 0., 0.);
+    if (big)
+        hipExtLaunchKernelGGL((k_gemm<T, true, false, 128>), dim3(big), block, 0, stream, ev ? ev[0] : nullptr, tail ? nullptr : (ev ? ev[1] : nullptr), 0,
+                              L, ld, gx, 0, F, (const T*)P, Tw, 0., 0., 0., 0., 0., 0., 0., 0., 0.);
+    if (tail)
+        hipExtLaunchKernelGGL((k_gemm<T, true, false, 64>), dim3(4 * tail), block, 0, stream, big ? nullptr : (ev ? ev[0] : nullptr), ev ? ev[1] : nullptr, 0,
+                              L, ld, gx, big, F, (const T*)P, Tw, 0., 0., 0., 0., 0., 0., 0., 0., 0.);
     if (hipGetLastError() != hipSuccess) return 1;
     // P = T * F^T + Qbar
-    hipExtLaunchKernelGGL((k_gemm<T, false, true>), grid, block, 0, stream, ev ? ev[2] : nullptr, ev ? ev[3] : nullptr, 0,
-                          L, ld, (const T*)Tw, F, P, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8]);
+    if (big)
+        hipExtLaunchKernelGGL((k_gemm<T, false, true, 128>), dim3(big), block, 0, stream, ev ? ev[2] : nullptr, tail ? nullptr : (ev ? ev[3] : nullptr), 0,
+                              L, ld, gx, 0, (const T*)Tw, F, P, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8]);
+    if (tail)
+        hipExtLaunchKernelGGL((k_gemm<T, false, true, 64>), dim3(4 * tail), block, 0, stream, big ? nullptr : (ev ? ev[2] : nullptr), ev ? ev[3] : nullptr, 0,
+                              L, ld, gx, big, (const T*)Tw, F, P, Q[0], Q[1], Q[2], Q[3], Q[4], Q[5], Q[6], Q[7], Q[8]);
     if (hipGetLastError() != hipSuccess) return 1;
     return 0;
 }
