@@ -20,13 +20,14 @@
 //                  (:150-160), H (:162-186), S, S^-1 (:270), K and M at the rows of U, the state at U -- and writes a
 //                  PLAN per correction: H, S^-1, the innovation, M(U[p],:), P_{s-1}(set_s, U[p]).   Latency-bound
 //                  (transcendentals); nothing in it is O(len).
-//   k_tick_panels  one thread per state index, no serial dependency left: replays the plan on its column of RP and
-//                  its row of CP and emits, per correction, R_s(:, j) (5 x len) and K_s(i,:) (len x 2), and the new
-//                  state vector.  The plan's coefficients are wave-uniform: they arrive as scalar loads and feed the
-//                  FMAs as SGPR operands.
+//   k_tick_panels  one quad of lanes per (state index, role), no serial dependency left: replays the plan (staged in
+//                  LDS) on its column of RP and its row of CP and emits, per correction, R_s(:, j) (5 x len) and
+//                  K_s(i,:) (len x 2), and the new state vector.
 //   k_tick_apply   THE pass over P: every tile is read once, carried through all m corrections in registers with the
-//                  K / R strips streamed from L2, and written once -- 2 len^2 w bytes per TICK instead of per
-//                  correction (or per pair).
+//                  K / R strips staged in LDS, and written once -- 2 len^2 w bytes per TICK instead of per correction
+//                  (or per pair).  k_tick_apply_units: the same for one large fp64 filter, a wave's columns in two
+//                  units so that loads and stores hide behind the arithmetic.
+//   (overlapped runs: k_tick_prep, tick_carry inside the next tick's k_tick_chain, k_tick_wait / k_tick_signal)
 //
 // Every floating-point operation on every element is the one k_update performs, in the same order, with the same
 // rounding to the storage type after each correction; only where it is executed has changed.  The result is therefore
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
                                                      double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
 {
     // posmap != null (overlapped runs): the strips at the NEXT tick's index set are also dropped into the compact arrays
-    // KU [J][2][NU], RU [J][5][NU], SU [NU] (state after the round) for k_tick_next
+    // KU [J][2][NU], RU [J][5][NU], SU [NU] (state after the round) for the next tick's chain (tick_carry)
     constexpr int NU = kTickNU;
     const int b = blockIdx.y;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (IDX * 4));

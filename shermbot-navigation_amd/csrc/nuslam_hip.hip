@@ -475,7 +475,7 @@ int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, boo
 }
 
 // strips + the pass over P of one round, on the handle's stream, from `plan`
-// `between`, if given, is enqueued between the strips and the pass (overlapped runs: k_tick_next)
+// `between`, if given, is enqueued between the strips and the pass (overlapped runs: the signal for the next chain)
 template <typename F>
 int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan, bool compact, F between)
 {
@@ -659,13 +659,14 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
 // nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
 // tick's markers while it enqueues this one.  Two free-running streams, no event between them inside the loop (a
 // cross-stream hipEvent cost 10-20 us per use here); the two hand-offs per tick are counters in device memory
-// (tick_signal / k_tick_wait):
-//   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> next(t) -> pass(t)        (P, state vector)
-//   chain stream      [next(t-1)] chain(t) -> [next(t)] chain(t+1) -> ...                     (a 35 x 35 block)
+// (tick_signal / tick_wait):
+//   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> signal -> pass(t)         (P, state vector)
+//   chain stream      [strips(t-1)] chain(t) -> [strips(t)] chain(t+1) -> ...                 (a 35 x 35 block)
 // prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read; strips(t)
-// also drops the gain / prior-row strips at that set into compact arrays; next(t) replays the round on the block and
-// applies predict(t+1): chain(t+1) starts from that -- while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic,
-// same bits as the one-stream order (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
+// also drops the gain / prior-row strips at that set into compact arrays; chain(t+1) -- one kernel, waiting inside for
+// the signal behind strips(t) -- first replays the round on the block and applies predict(t+1) (tick_carry), then runs
+// its corrections: all while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic, same bits as the one-stream order
+// (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
 int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
@@ -721,7 +722,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         const TickObs o = obs_of(t);
         const View v = h->view();
 
-        // ---- chain stream: chain(t): from P for the first tick (behind predict), from next(t-1)'s hand-off afterwards
+        // ---- chain stream: chain(t): from P for the first tick (behind predict), from the strips of tick t-1 afterwards
         if (t == t_begin) {
             HIPCHK(hipEventRecord(h->ov_start, h->stream));               // once per run
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_start, 0));
@@ -747,7 +748,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         prev_J = o.J;
         if (rc) return rc;
         h->seq_chain += h->B;
-        // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), next(t), the pass over P
+        // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), the signal, the pass over P
         if (more)
             DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 2, h->B), dim3(64), v, o, obs_of(t + 1),
                                        (const T*)h->P(), h->tk_posmap, h->tk_blk, (const int*)cnt_chain, h->seq_chain, timeouts)));
