@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
     __shared__ double mrowL[kDaSlots][8];
     __shared__ double nTR[kDaSlots][3], nTC[kDaSlots][3], nS[kDaSlots], nTD[kDaLm][4];
     __shared__ double Zl[2][kTickJ];
-    __shared__ double candH[kDaLm][11], candZ[kDaLm][2];
+    __shared__ double candZ[kDaLm][2];
     __shared__ int meet_sh[2];                // the reduced key of the next marker, whether every workgroup arrived
 
     // ---- prologue (k_da_begin): the tracked entries out of the covariance after predict
@@ -907,72 +907,81 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
         DCK(5);
         if (wave == 1 && t == 0) sv = nS[0];
 
-        // ---- waves 0, 1: columns 0..2 at this row (needs the row role's strips of slots 0..2) and the diagonal blocks;
-        // ---- waves 2, 3: what the next marker's candidates need of the new STATE: H (wave 2), z_hat (wave 3)
+        // ---- wave 1: columns 0..2 at this row (needs the row role's strips of slots 0..2), the diagonal blocks, and --
+        // everything a candidate's psi needs being then in THIS wave's hands -- the next marker's candidates up to
+        // psi^-1 (H from the new state, psi = H P H^T + R);  wave 3: their z_hat (three atan2, two sincos: the long pole
+        // of this phase);  waves 0, 2: the stores of the correction.
         const bool cand = !last && !(brk || seen == 0 || seen >= n) && lane < kDaLm && wg * kDaLm + lane + 1 <= seen;
         const int s0 = 3 + 2 * (lane < kDaLm ? lane : 0);               // slot of the candidate's first index
-        if (st >= 0 && wave == 1) {
-            const int par = st & 1;
-            double* TCn = d.TC[par ^ 1] + (size_t)b * 3 * ld;
-            double n3[3] = { e3[0], e3[1], e3[2] };
-            if (!nocorr) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
-            }
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (own && t < ld) st_agent(&TCn[(size_t)q * ld + t], n3[q]);
-                nTC[lane][q] = n3[q];
-                e3[q] = n3[q];
-            }
-            // (the stores of a correction are dealt over waves 0..2: each costs its wave ~0.1 us of issue, and wave 3's
-            // z_hat chain, ~1.3 us, is what this phase has to wait for anyway)
-            if (own && t < ld) {
-                double* sn = d.DS[par ^ 1] + (size_t)b * ld;
+        double cH[10], cPi[4];                                          // wave 1: the candidate's H and psi^-1
+        int csing = 0;
+        if (wave == 1) {
+            if (st >= 0) {
+                double n3[3] = { e3[0], e3[1], e3[2] };
                 if (!nocorr) {
-                    st_agent(&Kb[(size_t)(st * 2 + 0) * ld + t], Kl[(st * 2 + 0) * kDaSlots + lane]);
-                    st_agent(&Kb[(size_t)(st * 2 + 1) * ld + t], Kl[(st * 2 + 1) * kDaSlots + lane]);
-                }
-                st_agent(&sn[t], sv);
-                if (last) v.s_out[(size_t)b * ld + t] = sv;
-            }
-        } else if (st >= 0 && wave == 0) {
-            const int par = st & 1;
-            double* TDn = d.TD[par ^ 1] + (size_t)b * 4 * n;
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                const int idx = 64 * h2 + lane;                         // entry e of landmark lm: P(c_lm + (e & 1), c_lm + (e >> 1))
-                const int lm = idx >> 2, e = idx & 3;
-                const int k = wg * kDaLm + lm;
-                if (lm < kDaLm && k < n) {
-                    double val = nTD[lm][e];
-                    const int si = 3 + 2 * lm + (e & 1), sj = 3 + 2 * lm + (e >> 1);
-                    if (!nocorr) val = p1_entry<T>(mrowL[si], rcolL[sj], val, mrowL[si][5], mrowL[si][6]);
-                    st_agent(&TDn[(size_t)e * n + k], val);
-                    nTD[lm][e] = val;
+                    for (int q = 0; q < 3; ++q) n3[q] = p1_entry<T>(m5, rcolL[q], e3[q], bef, aft);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    nTC[lane][q] = n3[q];
+                    e3[q] = n3[q];
+                }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int idx = 64 * h2 + lane;                     // entry e of landmark lm: P(c_lm + (e & 1), c_lm + (e >> 1))
+                    const int lm = idx >> 2, e = idx & 3;
+                    const int k = wg * kDaLm + lm;
+                    if (lm < kDaLm && k < n) {
+                        double val = nTD[lm][e];
+                        const int si = 3 + 2 * lm + (e & 1), sj = 3 + 2 * lm + (e >> 1);
+                        if (!nocorr) val = p1_entry<T>(mrowL[si], rcolL[sj], val, mrowL[si][5], mrowL[si][6]);
+                        nTD[lm][e] = val;
+                    }
                 }
             }
-            if (own && t < L && !nocorr) {
+            if (cand) {
+                double pb[5][5], psi[4];                                // pb[q][q2] = P(set[q2], set[q])
+                jacobian_compact(nS[1], nS[2], nS[s0], nS[s0 + 1], cH);                   // :212
 #pragma unroll
-                for (int q = 0; q < 5; ++q) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rcolL[lane][q]);
+                for (int q = 0; q < 5; ++q)
+#pragma unroll
+                    for (int q2 = 0; q2 < 5; ++q2) {
+                        double val;
+                        if (q2 < 3) val = nTR[q < 3 ? q : s0 + (q - 3)][q2];
+                        else if (q < 3) val = nTC[s0 + (q2 - 3)][q];                      // (written by this wave just above)
+                        else val = nTD[lane][(q2 - 3) + 2 * (q - 3)];
+                        pb[q][q2] = val;
+                    }
+                innovation_cov_block(pb, cH, v.R, psi);                 // :215
+                csing = inv2(psi, cPi);
+            }
+        } else if (wave == 0) {
+            if (st >= 0 && own) {
+                const int par = st & 1;
+                double* sn = d.DS[par ^ 1] + (size_t)b * ld;
+                if (t < L && !nocorr) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rcolL[lane][q]);
+                }
+                if (t < ld) {
+                    if (!nocorr) {
+                        st_agent(&Kb[(size_t)(st * 2 + 0) * ld + t], Kl[(st * 2 + 0) * kDaSlots + lane]);
+                        st_agent(&Kb[(size_t)(st * 2 + 1) * ld + t], Kl[(st * 2 + 1) * kDaSlots + lane]);
+                    }
+                    const double sx = nS[lane];
+                    st_agent(&sn[t], sx);
+                    if (last) v.s_out[(size_t)b * ld + t] = sx;
+                }
             }
         } else if (wave == 2) {
-            if (cand) {
-                double Hc[10];
-                jacobian_compact(nS[1], nS[2], nS[s0], nS[s0 + 1], Hc);                    // :212
-#pragma unroll
-                for (int k = 0; k < 10; ++k) candH[lane][k] = Hc[k];
-            }
-            if (st >= 0) {
-                // rows 0..2 at this column go out from here, off the prior-row wave's critical path
+            if (st >= 0 && own && t < L) {
                 const int par = st & 1;
                 double* TRn = d.TR[par ^ 1] + (size_t)b * 3 * ld;
-                if (own && t < L) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) st_agent(&TRn[(size_t)q * ld + t], nTR[lane][q]);
-                }
+                for (int q = 0; q < 3; ++q) st_agent(&TRn[(size_t)q * ld + t], nTR[lane][q]);
             }
-        } else if (wave == 3) {
+        } else {
             if (cand) {
                 double zr, zb;
                 measurement(nS[0], nS[1], nS[2], nS[s0], nS[s0 + 1], zr, zb);              // :218
@@ -984,33 +993,37 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
         __syncthreads();
         DCK(7);
 
-        // ---- the candidates of marker st + 1 against what this correction (or the prologue) left: k_associate
+        // ---- wave 1: the candidates' distances against the marker (k_associate), the key;  waves 0, 2: what wave 1 left
+        // in LDS for the other workgroups (columns 0..2, the diagonal blocks) goes out
         if (wave == 0) {
+            if (st >= 0) {
+                double* TDn = d.TD[(st & 1) ^ 1] + (size_t)b * 4 * n;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int idx = 64 * h2 + lane;
+                    const int lm = idx >> 2, e = idx & 3;
+                    const int k = wg * kDaLm + lm;
+                    if (lm < kDaLm && k < n) st_agent(&TDn[(size_t)e * n + k], nTD[lm][e]);
+                }
+            }
+        } else if (wave == 2) {
+            if (st >= 0 && own && t < ld) {
+                double* TCn = d.TC[(st & 1) ^ 1] + (size_t)b * 3 * ld;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) st_agent(&TCn[(size_t)q * ld + t], nTC[lane][q]);
+            }
+        } else if (wave == 1) {
             int key1 = kNoKey;
             if (cand) {
                 const double r = Zl[0][st + 1], phi = Zl[1][st + 1];
-                double pb[5][5], Hc[10], psi[4], psi_inv[4];            // pb[q][q2] = P(set[q2], set[q])
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-#pragma unroll
-                    for (int q2 = 0; q2 < 5; ++q2) {
-                        double val;
-                        if (q2 < 3) val = nTR[q < 3 ? q : s0 + (q - 3)][q2];
-                        else if (q < 3) val = nTC[s0 + (q2 - 3)][q];
-                        else val = nTD[lane][(q2 - 3) + 2 * (q - 3)];
-                        pb[q][q2] = val;
-                    }
-#pragma unroll
-                for (int k = 0; k < 10; ++k) Hc[k] = candH[lane][k];
                 const double zr = candZ[lane][0], zb = candZ[lane][1];
-                innovation_cov_block(pb, Hc, v.R, psi);                 // :215
                 const double dz0 = r - zr, dz1 = phi - zb;             // :229
                 int code = -1;
-                if (inv2(psi, psi_inv)) code = 2;
+                if (csing) code = 2;
                 else {
                     double w0 = 0.0, w1 = 0.0, dd2 = 0.0;               // (dz^T psi^-1) dz, :231
-                    w0 = fma(dz0, psi_inv[0], w0); w0 = fma(dz1, psi_inv[1], w0);
-                    w1 = fma(dz0, psi_inv[2], w1); w1 = fma(dz1, psi_inv[3], w1);
+                    w0 = fma(dz0, cPi[0], w0); w0 = fma(dz1, cPi[1], w0);
+                    w1 = fma(dz0, cPi[2], w1); w1 = fma(dz1, cPi[3], w1);
                     dd2 = fma(w0, dz0, dd2); dd2 = fma(w1, dz1, dd2);
                     if (dd2 < 0.01) code = 0;                                           // :238
                     else if ((dd2 > 0.01) && (dd2 < 60)) code = 1;                      // :243
@@ -1020,9 +1033,9 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     // a match: update() will want exactly these (same state, same covariance, same functions)
                     double* ap = d.AP[(st + 1) & 1] + ((size_t)b * n + wg * kDaLm + lane) * 16;
 #pragma unroll
-                    for (int k = 0; k < 10; ++k) st_agent(ap + k, Hc[k]);
+                    for (int k = 0; k < 10; ++k) st_agent(ap + k, cH[k]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) st_agent(ap + 10 + k, psi_inv[k]);
+                    for (int k = 0; k < 4; ++k) st_agent(ap + 10 + k, cPi[k]);
                     st_agent(ap + 14, zr);
                     st_agent(ap + 15, zb);
                 }
