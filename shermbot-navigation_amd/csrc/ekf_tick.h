@@ -38,6 +38,7 @@ namespace nuslam {
 
 constexpr int kTickJ = 16;                 // corrections per round (a tick with more markers runs several rounds)
 constexpr int kTickNU = 3 + 2 * kTickJ;    // panel indices
+constexpr int kTickDump = 512;             // doubles behind each strip buffer: where k_tick_panels' lanes that own nothing store
 
 // the markers of one round, for every filter
 struct TickObs {
@@ -638,7 +639,7 @@ constexpr int kQuadRows = (kTickNU + 3) / 4;              // panel positions per
 // IDX = state indices per workgroup (64: 8 waves; 32: 4 waves, one per SIMD -- the kernel is VALU-issue-bound, so a single
 // filter, whose 2003 indices fill only a fraction of the chip anyway, takes the smaller groups on twice the CUs).
 template <typename T, int IDX>
-__global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
+__global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                      double* __restrict__ Rbuf, const int* __restrict__ posmap,
                                                      double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
@@ -684,6 +685,16 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
         // ---- column t of the five-row strips R_s and of the row panel
         const bool live = t < L;
         const int pm = (posmap && live && k == 0) ? posmap[(size_t)b * ld + t] : -1;
+        // Stores without branches: a lane that owns no column / no compact slot stores into a dump area behind the buffer.
+        // (An `if` around the stores ends the basic block: with sixteen unrolled corrections the scheduler could then not
+        // move a correction's LDS reads of the plan above the previous correction's arithmetic, and every correction
+        // started with exposed LDS round trips -- one wave per SIMD here, nothing else to run meanwhile.)
+        double* const rdump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
+        double* const rdst = (live && k == 0) ? Rb + t : rdump;
+        const size_t rstep = (live && k == 0) ? (size_t)ld : 0;
+        double* const rudump = RU ? RU + (size_t)v.B * kTickJ * 5 * NU + (threadIdx.x & (kTickDump - 1)) : nullptr;
+        double* const rudst = pm >= 0 ? RU + (size_t)b * kTickJ * 5 * NU + pm : rudump;
+        const size_t rustep = pm >= 0 ? (size_t)NU : 0;
         const T* col = Pb + (size_t)(live ? t : 0) * ld;
         double RP[kQuadRows];
 #pragma unroll
@@ -697,13 +708,11 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
                 // P_{s-1}(set_s[q], t): positions 0, 1, 2, pos, pos + 1 live in lanes 0, 1, 2, pos & 3, (pos + 1) & 3
                 const double rs[5] = { quad_bcast(RP[0], 0), quad_bcast(RP[0], 1), quad_bcast(RP[0], 2),
                                        quad_bcast(RP[pos >> 2], pos & 3), quad_bcast(RP[(pos + 1) >> 2], (pos + 1) & 3) };
-                if (live && k == 0) {
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
-                }
-                if (pm >= 0) {
+                for (int q = 0; q < 5; ++q) rdst[(size_t)(st * 5 + q) * rstep] = rs[q];
+                if (posmap) {                                           // (uniform)
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + pm] = rs[q];
+                    for (int q = 0; q < 5; ++q) rudst[(size_t)(st * 5 + q) * rustep] = rs[q];
                 }
 #pragma unroll
                 for (int j = 0; j < kQuadRows; ++j) {
@@ -726,6 +735,12 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
         const bool live = t < ld;
         const int tr = live ? t : 0;
         const int pm = (posmap && live && k == 0) ? posmap[(size_t)b * ld + t] : -1;
+        double* const kdump = Kbuf + (size_t)v.B * kTickJ * 2 * ld + (threadIdx.x & (kTickDump - 1));
+        double* const kdst = (live && k == 0) ? Kb + t : kdump;
+        const size_t kstep = (live && k == 0) ? (size_t)ld : 0;
+        double* const kudump = KU ? KU + (size_t)v.B * kTickJ * 2 * NU + (threadIdx.x & (kTickDump - 1)) : nullptr;
+        double* const kudst = pm >= 0 ? KU + (size_t)b * kTickJ * 2 * NU + pm : kudump;
+        const size_t kustep = pm >= 0 ? (size_t)NU : 0;
         double CP[kQuadRows];
 #pragma unroll
         for (int j = 0; j < kQuadRows; ++j) CP[j] = (double)Pb[(size_t)Uk[j] * ld + tr];
@@ -751,13 +766,11 @@ __global__ __launch_bounds__(IDX * 8) void k_tick_panels(View v, TickObs o, cons
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
                 gain_row(pc, Hc, Si, t, setv, K, m);
-                if (live && k == 0) {
-                    Kb[(size_t)(st * 2 + 0) * ld + t] = K[0];
-                    Kb[(size_t)(st * 2 + 1) * ld + t] = K[1];
-                }
-                if (pm >= 0) {
-                    KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + pm] = K[0];
-                    KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + pm] = K[1];
+                kdst[(size_t)(st * 2 + 0) * kstep] = K[0];
+                kdst[(size_t)(st * 2 + 1) * kstep] = K[1];
+                if (posmap) {                                           // (uniform)
+                    kudst[(size_t)(st * 2 + 0) * kustep] = K[0];
+                    kudst[(size_t)(st * 2 + 1) * kustep] = K[1];
                 }
                 const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
                 double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;

@@ -414,8 +414,8 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<double, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_panels<float, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
-    HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
-    HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * (size_t)h->B * kTickJ * 5 * h->ld));
+    HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * ((size_t)h->B * kTickJ * 2 * h->ld + kTickDump)));
+    HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * ((size_t)h->B * kTickJ * 5 * h->ld + kTickDump)));
     return NUSLAM_OK;
 }
 
@@ -682,8 +682,8 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * B));
         HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * B * kTickNU * kTickNU));
         HIPCHK(hipMalloc(&h->tk_posmap, sizeof(int) * B * h->ld));
-        HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * B * kTickJ * 2 * kTickNU));
-        HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * B * kTickJ * 5 * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * (B * kTickJ * 2 * kTickNU + kTickDump)));
+        HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * (B * kTickJ * 5 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_SU, sizeof(double) * B * kTickNU));
         HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 4));
         HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 4, h->stream));
