@@ -635,11 +635,18 @@ __device__ inline double quad_bcast(double x, int k)     // lane k of every quad
 }
 
 constexpr int kQuadRows = (kTickNU + 3) / 4;              // panel positions per lane
+#ifdef NUSLAM_CHAIN_CLOCK
+__device__ long long g_panels_clock[2][20];               // debug builds: per role, 100 MHz ticks: prologue, 16 corrections, tail
+#define PCK(r, k) do { if (blockIdx.x == 1 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 1) == 0) { \
+        const long long n__ = (long long)wall_clock64(); g_panels_clock[r][k] = n__ - pct; pct = n__; } } while (0)
+#else
+#define PCK(r, k) do { } while (0)
+#endif
 
 // IDX = state indices per workgroup (64: 8 waves; 32: 4 waves, one per SIMD -- the kernel is VALU-issue-bound, so a single
 // filter, whose 2003 indices fill only a fraction of the chip anyway, takes the smaller groups on twice the CUs).
 template <typename T, int IDX>
-__global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
+__global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX == 32 ? 2 : 4))) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                      double* __restrict__ Rbuf, const int* __restrict__ posmap,
                                                      double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
@@ -657,6 +664,9 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
     double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
     double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
 
+#ifdef NUSLAM_CHAIN_CLOCK
+    long long pct = (long long)wall_clock64();
+#endif
     extern __shared__ double plan_l[];                                  // [J] TickStep
     {
         const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
@@ -700,19 +710,30 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
         for (int j = 0; j < kQuadRows; ++j) RP[j] = (double)col[Uk[j]];
         __syncthreads();
+        PCK(0, 0);
+        // which corrections change P: one LDS read and a ballot instead of a flag read (and its latency) at the top of
+        // every correction; the corrections themselves run WITHOUT a branch around them -- a skipped one computes on its
+        // (stale) plan entry and keeps nothing -- so that the sixteen of them are one basic block to the scheduler
+        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[(threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0].skip == 0) & 0xffffu;
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {             // (no break / continue: the loop must unroll, RP is indexed by st)
             const TickStep* ps = pls + (st < J ? st : 0);
-            if (st < J && !ps->skip) {
+            PCK(0, 1 + st);
+            const bool act = (actmask >> st) & 1u;
+            if (IDX == 32 || act) {                       // (IDX == 64, batches: a branch per correction keeps the register count at 110)
                 const int pos = 3 + 2 * st;
                 // P_{s-1}(set_s[q], t): positions 0, 1, 2, pos, pos + 1 live in lanes 0, 1, 2, pos & 3, (pos + 1) & 3
                 const double rs[5] = { quad_bcast(RP[0], 0), quad_bcast(RP[0], 1), quad_bcast(RP[0], 2),
                                        quad_bcast(RP[pos >> 2], pos & 3), quad_bcast(RP[(pos + 1) >> 2], (pos + 1) & 3) };
+                double* const rd = act ? rdst : rdump;
+                const size_t rsp = act ? rstep : 0;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) rdst[(size_t)(st * 5 + q) * rstep] = rs[q];
+                for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
                 if (posmap) {                                           // (uniform)
+                    double* const rud = act ? rudst : rudump;
+                    const size_t rusp = act ? rustep : 0;
 #pragma unroll
-                    for (int q = 0; q < 5; ++q) rudst[(size_t)(st * 5 + q) * rustep] = rs[q];
+                    for (int q = 0; q < 5; ++q) rud[(size_t)(st * 5 + q) * rusp] = rs[q];
                 }
 #pragma unroll
                 for (int j = 0; j < kQuadRows; ++j) {
@@ -726,7 +747,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
                     const double m6 = ps->MP[pc][6];
                     const double m[5] = { m01.v[0], m01.v[1], m23.v[0], m23.v[1], m45.v[0] };
                     const double nv = p1_entry<T>(m, rs, RP[j], m45.v[1], m6);
-                    RP[j] = on ? nv : RP[j];
+                    RP[j] = (on && act) ? nv : RP[j];
                 }
             }
         }
@@ -746,16 +767,23 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
         for (int j = 0; j < kQuadRows; ++j) CP[j] = (double)Pb[(size_t)Uk[j] * ld + tr];
         double sv = v.s_in[(size_t)b * ld + tr];
         __syncthreads();
+        PCK(1, 0);
+        const int l16 = (threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0;
+        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[l16].skip == 0) & 0xffffu;
+        const unsigned initmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[l16].init != 0) & 0xffffu;
+        const int c_lane = pls[l16].c;                                  // correction (lane & 15)'s landmark index
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {
             const TickStep* ps = pls + (st < J ? st : 0);
-            const int c = ps->c;
-            const bool init = ps->init != 0;
-            if (st < J && ps->skip && init) {                           // the landmark was initialised before update() threw
+            PCK(1, 1 + st);
+            const int c = __builtin_amdgcn_readlane(c_lane, st);
+            const bool act = (actmask >> st) & 1u;
+            const bool init = (initmask >> st) & 1u;
+            if (st < J && !act && init) {                               // the landmark was initialised before update() threw
                 if (t == c) sv = ps->lxy[0];
                 if (t == c + 1) sv = ps->lxy[1];
             }
-            if (st < J && !ps->skip) {
+            if (IDX == 32 || act) {
                 const int pos = 3 + 2 * st;
                 const int setv[5] = { 0, 1, 2, c, c + 1 };
                 const double pc[5] = { quad_bcast(CP[0], 0), quad_bcast(CP[0], 1), quad_bcast(CP[0], 2),
@@ -766,11 +794,15 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
                 gain_row(pc, Hc, Si, t, setv, K, m);
-                kdst[(size_t)(st * 2 + 0) * kstep] = K[0];
-                kdst[(size_t)(st * 2 + 1) * kstep] = K[1];
+                double* const kd = act ? kdst : kdump;
+                const size_t ksp = act ? kstep : 0;
+                kd[(size_t)(st * 2 + 0) * ksp] = K[0];
+                kd[(size_t)(st * 2 + 1) * ksp] = K[1];
                 if (posmap) {                                           // (uniform)
-                    kudst[(size_t)(st * 2 + 0) * kustep] = K[0];
-                    kudst[(size_t)(st * 2 + 1) * kustep] = K[1];
+                    double* const kud = act ? kudst : kudump;
+                    const size_t kusp = act ? kustep : 0;
+                    kud[(size_t)(st * 2 + 0) * kusp] = K[0];
+                    kud[(size_t)(st * 2 + 1) * kusp] = K[1];
                 }
                 const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
                 double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;
@@ -781,7 +813,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
                 // :276 -- the chain formed exactly this sum for the heading and wrapped it (one wave there instead of a
                 // 450-instruction straggler here, sixteen times)
                 if (t == 0) s0 = ps->MP[0][7];
-                sv = s0;
+                sv = act ? s0 : sv;
 #pragma unroll
                 for (int j = 0; j < kQuadRows; ++j) {
                     if (4 * j >= 3 && 4 * j + 3 < pos + 2) continue;    // no lane of the quad is live here
@@ -793,7 +825,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, 2)))
                     const double r4 = ps->BR[pcx][4];
                     const double r[5] = { r01.v[0], r01.v[1], r23.v[0], r23.v[1], r4 };
                     const double nv = p1_entry<T>(m, r, CP[j], bef, aft);
-                    CP[j] = on ? nv : CP[j];
+                    CP[j] = (on && act) ? nv : CP[j];
                 }
             }
         }

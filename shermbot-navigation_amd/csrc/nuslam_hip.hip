@@ -1334,6 +1334,12 @@ extern "C" int nuslam_debug_da_clock(long long out[64])
 }
 #endif
 #ifdef NUSLAM_CHAIN_CLOCK
+extern "C" int nuslam_debug_panels_clock(long long out[40])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_panels_clock), sizeof(long long) * 40));
+    return NUSLAM_OK;
+}
 extern "C" int nuslam_debug_chain_clock(long long out[32])
 {
     HIPCHK(hipDeviceSynchronize());
