@@ -22,4 +22,6 @@ for t in range(30, 40):
     out = (C.c_longlong * 40)(); L.nuslam_debug_panels_clock(out); acc.append(list(out))
 a = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(2, 20) * 0.01
 for r in range(2):
+    if r == 0:
+        print("role 0 prologue split: kernel entry -> before the plan loads %.2f us, plan staging issued %.2f us, gathers issued %.2f us, barrier passed %.2f us" % (a[0, 17], a[0, 18], a[0, 19], a[0, 0]))
     print("role %d: prologue %.2f us; per correction " % (r, a[r, 0]) + " ".join("%.2f" % x for x in a[r, 2:17]) + " | first stamp %.2f" % a[r, 1])
