@@ -672,10 +672,12 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
         Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
         const int n16 = J * (int)(sizeof(TickStep) / 16);
+        PCK(0, 17);
         // (4.6 us of this kernel's ~18 at N = 1000: a CU moves a 1 KB wave-load in ~0.25 us here; copying only the rows
         // that are read -- half of them -- through predicated pieces cost more in address arithmetic than it saved)
         for (int e = threadIdx.x; e < n16; e += IDX * 8) dst[e] = src[e];
     }
+    PCK(0, 18);
     // this lane's positions p = 4 j + k and the state indices behind them
     int Uk[kQuadRows];
 #pragma unroll
@@ -711,6 +713,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         double RP[kQuadRows];
 #pragma unroll
         for (int j = 0; j < kQuadRows; ++j) RP[j] = (double)col[Uk[j]];
+        PCK(0, 19);
         __syncthreads();
         PCK(0, 0);
         // which corrections change P: one LDS read and a ballot instead of a flag read (and its latency) at the top of
