@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define NUSLAM_HIP_ABI_VERSION 1
+/* 2: nuslam_batch_stats is 2*len + 6 doubles (trace(P) at [2*len + 4]); the status enum gained NUSLAM_E_SYNC / _COMM /
+ *    _CAPACITY; nuslam_batch_set_pass_variant selects between the rank-2m pass and the exact chain; NUSLAM_K_TICK_RANK */
+#define NUSLAM_HIP_ABI_VERSION 2
 
 typedef enum {
     NUSLAM_OK = 0,
@@ -190,9 +192,16 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
  * markers from the resident trace; the streams hand over through device counters, every wait bounded).  Same bits
  * either way.  enable < 0 (default): on for a handle of one filter, off for batches (measured). */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
-/* Which instantiation of the pass over the covariance a tick pipeline uses for one large fp64 filter: 0 (default) = the
- * two-unit kernel when the pass has the chip to itself, the plain one beside the chain of an overlapped run; 1 = always
- * the plain one (profiling: counter passes serialise the dispatches, so an overlapped run cannot be counted).  Same bits. */
+/* How a tick pipeline's ONE pass over the covariance applies the round's corrections.
+ *   0 (default)  as a rank-2m update on the matrix cores: update()'s P <- (I - K H) P (slam_library.cpp:279) re-associated
+ *                as P - K (H P), all corrections of the round in one v_mfma_f64 accumulation per tile -- 2 FMAs per element
+ *                and correction instead of 7, a streaming kernel.  Same algebra, different rounding: agrees with the exact
+ *                chain to ~1e-13 per entry from a warm state, NOT bit for bit.  A round that holds a first sighting (the
+ *                INT_MAX diagonal of slam_library.cpp:30 is being cancelled) is applied by the exact chain, decided per
+ *                filter on the device from the round's plan.
+ *   1            always the exact chain (bit-identical to one update() per marker), plain kernel
+ *   2            always the exact chain, the two-unit kernel for one large fp64 filter that has the chip to itself
+ *   10 + k       as 0 with tile shape k = 0..3 (measurement only) */
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */
@@ -214,6 +223,12 @@ typedef struct nuslam_sim_params {
                                           clusterPoints -> classifyCluster -> circleFit (nuslam/src/landmarks.cpp:63, 82-108),
                                           all on the device; data association only (scan markers carry no identity) */
     double lidar_min_range, lidar_max_range;   /* nuturtlesim/config/scan_params.yaml: minimum_range 0.05, maximum_range 1.0 */
+    double fov;                        /* extension: half-angle (rad) of the marker sensor's field of view; <= 0: all around (the
+                                          reference's behaviour).  The reference's update() does not wrap the bearing innovation
+                                          (slam_library.cpp:272), so a tube behind the robot yields a 2 pi innovation: Monte-Carlo
+                                          worlds that are to stay in the filter's working regime use a limited field of view */
+    double min_range;                  /* extension, with fov > 0: tubes nearer than this are not reported either (at a few cm the
+                                          marker noise alone carries a bearing across the +-pi cut) */
 } nuslam_sim_params;
 /* Generate `ticks` ticks for every filter: landmarks = {x0, y0, x1, y1, ...} (n_world tubes, shared by all filters),
  * cmd = ticks x (dth, dx) commanded body twists (the /cmd_vel stream, shared).  Filter b draws from the random streams
@@ -259,7 +274,8 @@ typedef enum {
     NUSLAM_K_TICK_NEXT = 10,   /* (no longer launched: the replay of the next tick's starting block is part of NUSLAM_K_TICK_CHAIN) */
     NUSLAM_K_DA_BEGIN = 11,    /* unknown-association tick pipeline: tracked rows / columns / diagonal blocks out of P */
     NUSLAM_K_DA_STEP = 12,     /* ... one correction: association verdict, strips, tracked entries, next marker's candidates */
-    NUSLAM_K_COUNT = 13
+    NUSLAM_K_TICK_RANK = 13,   /* tick pipeline: the one pass over P as a rank-2m update on the matrix cores -- the HBM-bound kernel */
+    NUSLAM_K_COUNT = 14
 } nuslam_kernel_id;
 /* When enabled, every launch of the listed kernels carries its own pair of HIP events on the handle's
  * stream (hipExtLaunchKernelGGL start/stop events: the dispatch's own begin/end timestamps). */

@@ -103,6 +103,12 @@ typedef struct {
     double lidar;                      /* != 0: markers come from the simulated lidar scan through the landmarks node's
                                           cluster / classify / circle-fit chain instead of set_rel_markers (unused here) */
     double lidar_min_range, lidar_max_range;   /* scan_params.yaml minimum_range / maximum_range */
+    double fov;                        /* extension: half-angle (rad) of the marker sensor's field of view; <= 0: all around (the
+                                          reference's behaviour).  The reference's update() does not wrap the bearing innovation
+                                          (slam_library.cpp:272), so a tube behind the robot yields a 2 pi innovation: Monte-Carlo
+                                          worlds that are to stay in the filter's working regime use a limited field of view */
+    double min_range;                  /* extension, with fov > 0: tubes nearer than this are not reported either (at a few cm the
+                                          marker noise alone carries a bearing across the +-pi cut) */
 } orc_sim_params;
 void   orc_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4]);
 void   orc_sim_normal_pair(unsigned long long seed, unsigned filter, unsigned tick, unsigned stream, unsigned idx,

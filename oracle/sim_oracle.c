@@ -138,6 +138,9 @@ long long orc_simulate(const orc_sim_params* p, const double* landmarks, int n, 
             const double dy = landmarks[2 * i + 1] - turtle[3];
             dist[i] = sqrt((dx * dx) + (dy * dy));                                  /* :299 */
             keep[i] = (p->max_range <= 0.0 || !(dist[i] > p->max_range)) ? 1 : 0;   /* :300 */
+            /* extension (fov > 0): within +-fov of the heading -- (tube - robot) . heading >= cos(fov) d */
+            if (p->fov > 0.0 && (!((cos(turtle[4]) * dx) + (sin(turtle[4]) * dy) >= cos(p->fov) * dist[i]) || dist[i] < p->min_range)) keep[i] = 0;
+            if (!keep[i]) dist[i] = INFINITY;        /* a gated tube takes no part in the ranking below */
             in_range += keep[i];
         }
         if (in_range > m) {                          /* keep the m nearest; ties go to the lower tube index */
@@ -145,8 +148,7 @@ long long orc_simulate(const orc_sim_params* p, const double* landmarks, int n, 
                 if (!keep[i]) continue;
                 int rank = 0;
                 for (int j = 0; j < n; ++j) {
-                    const int inr = (p->max_range <= 0.0 || !(dist[j] > p->max_range));
-                    if (inr && (dist[j] < dist[i] || (dist[j] == dist[i] && j < i))) ++rank;
+                    if (dist[j] < INFINITY && (dist[j] < dist[i] || (dist[j] == dist[i] && j < i))) ++rank;
                 }
                 if (rank >= m) keep[i] = 2;          /* in range but not kept */
             }

@@ -204,8 +204,10 @@ __global__ __launch_bounds__(256) void k_sim_markers(SimArg a)
         const double dx = a.lm[2 * i] - x;
         const double dy = a.lm[2 * i + 1] - y;
         const double d = sqrt((dx * dx) + (dy * dy));            // :299
-        const bool inr = (p.max_range <= 0.0) || !(d > p.max_range);   // :300
-        sh_dist[i] = d;
+        bool inr = (p.max_range <= 0.0) || !(d > p.max_range);   // :300
+        // extension (fov > 0): the tube must lie within +-fov of the robot's heading -- (tube - robot) . heading >= cos(fov) d
+        if (p.fov > 0.0) inr = inr && ((cos(th) * dx) + (sin(th) * dy) >= cos(p.fov) * d) && !(d < p.min_range);
+        sh_dist[i] = inr ? d : INFINITY;                         // (a gated tube takes no part in the ranking below)
         sh_keep[i] = inr ? 1 : 0;
         mine += inr ? 1 : 0;
     }
@@ -220,8 +222,7 @@ __global__ __launch_bounds__(256) void k_sim_markers(SimArg a)
             int rank = 0;
             for (int j = 0; j < n; ++j) {
                 const double dj = sh_dist[j];
-                const bool inr = (p.max_range <= 0.0) || !(dj > p.max_range);
-                rank += (inr && (dj < di || (dj == di && j < i))) ? 1 : 0;
+                rank += (dj < INFINITY && (dj < di || (dj == di && j < i))) ? 1 : 0;
             }
             if (rank >= m) sh_keep[i] = 2;                       // own flag only; the rank loop reads distances
         }

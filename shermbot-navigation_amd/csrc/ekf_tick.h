@@ -56,7 +56,10 @@ struct TickObs {
 // what one correction leaves for k_tick_panels and k_tick_apply (per filter, per marker)
 struct alignas(16) TickStep {
     int skip;              // the marker changes nothing in P (gray zone, break, bad id, singular S)
-    int init;              // initializeLandmark ran: state rows c, c+1 become lxy before the correction (or instead of it)
+    int init;              // bit 0: initializeLandmark ran: state rows c, c+1 become lxy before the correction (or instead of it);
+                           // bit 1: the landmark's covariance still carried the INT_MAX diagonal of slam_library.cpp:30 (with ids
+                           // in order the same corrections; a known id BELOW an earlier one is never initialised by the
+                           // caller's chain, slam.cpp:295, yet its first update cancels INT_MAX all the same)
     int c;                 // first state index of the landmark
     int id;                // resolved id
     double Hc[10], Sinv[4], dz[2], lxy[2];
@@ -78,6 +81,7 @@ struct TickCarry {
     int wait_target;
     int* timeouts;
     int Jt;                    // markers of the previous tick's round
+    int rank;                  // != 0: that round's pass is the rank-2m one unless its plan holds a first sighting (round_flags)
     TwistArg tw;               // this tick's twist
 };
 
@@ -86,6 +90,29 @@ struct TickCarry {
 __device__ inline void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// (H_s P_{s-1})(r, j) from the five prior rows at column j: ascending-q FMA chain -- the ONE definition every producer
+// and consumer of V strips uses (k_tick_panels, k_tick_vstrips, tick_carry), so that they agree bit for bit
+__device__ inline double hp_entry(const double* Hc, const double rs[5], int r)
+{
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) a = fma(Hc[r + 2 * q], rs[q], a);
+    return a;
+}
+
+// Which corrections of a round change P (bit s: correction s is live) and whether the round holds a first sighting
+// (`init` != 0: the INT_MAX diagonal of slam_library.cpp:30 is about to be cancelled) -- from the plan's flags,
+// wave-uniform.  A round with a first sighting is applied by the exact chain (k_tick_apply), every other round by the
+// rank-2m pass (ekf_rank.h); both kernels and tick_carry evaluate this one predicate.
+__device__ inline void round_flags(const TickStep* pl, int J, unsigned& actmask, bool& any_init)
+{
+    const int lane = threadIdx.x & 63;
+    const int l16 = lane < kTickJ ? lane : 0;
+    const int sk = pl[l16].skip, in = pl[l16].init;
+    actmask = (unsigned)__ballot(lane < J && sk == 0) & 0xffffu;
+    any_init = ((unsigned)__ballot(lane < J && in != 0) & 0xffffu) != 0u;
 }
 
 // Hand-offs BETWEEN kernels of the two streams of an overlapped run (nuslam_batch_set_overlap): a monotonic counter in
@@ -161,6 +188,8 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
     double* SF = carry_lds + (kTickJ - SPLIT) * RS + kTickJ * 12;       // [NU + 1]
     double* Rlo = &FBs[0][0];
     __shared__ int canon[NU + 1];
+    // the arithmetic of the pass that is rewriting the covariance meanwhile: the exact chain (p1_entry) or the rank-2m sum
+    const bool rank = cy.rank != 0 && !__syncthreads_or(tid < Jt && pl[tid < kTickJ ? tid : 0].init != 0);
 
     for (int e = tid; e < kTickJ * 12; e += NT) {
         const int st = e / 12, f = e % 12;
@@ -194,6 +223,27 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
     for (int k = 0; k < NE; ++k) E[k] = cy.blk[(size_t)b * NU * NU + a * NU + b0 + k];
     __syncthreads();
 
+    if (rank) {
+        // k_tick_rank's sum on these entries: acc = fma(V_f(column), -K_f(row), acc), f = 2 s + r ascending, as the f64 MFMA
+        // accumulates it (a k-ordered fma chain); rounded to the storage type once, as that kernel stores it
+#pragma unroll
+        for (int st = 0; st < kTickJ; ++st) {
+            const double* ps = PS[st];
+            if (st < Jt && ps[11] == 0.0) {
+                const double* Rst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    double r[5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) r[q] = Rst[q * (NU + 1) + b0 + k];
+                    E[k] = fma(hp_entry(ps, r, 0), -K0[st], E[k]);
+                    E[k] = fma(hp_entry(ps, r, 1), -K1[st], E[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) E[k] = (double)(T)E[k];
+    } else {
 #pragma unroll
     for (int st = 0; st < kTickJ; ++st) {
         const double* ps = PS[st];
@@ -218,6 +268,7 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
                 E[k] = p1_entry<T>(m, r, E[k], bef, aft);
             }
         }
+    }
     }
     __syncthreads();                                                    // (the scratch block held R until here)
     if (mine) {
@@ -485,6 +536,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         CK(1);
         if (pend) { bcur ^= 1; pend = false; }
         const double (*B0)[NU + 1] = BK[bcur];                          // the block before THIS correction, complete
+        const int fresh = B0[pos][pos] > 1.0e9 ? 2 : 0;                 // INT_MAX (2.1e9) still on the landmark's diagonal
 
         // ---- phase 2: the bearing against the wrapped heading (wave 1) | K, M at the rows of U (wave 0), the prior
         // rows at the columns of U (wave 2)
@@ -522,7 +574,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         if (sing) {                                                     // singular S: update() throws after the init
             if (status == 0) status = kStatusSingular;
             if (tid == 0) {
-                ps->skip = 1; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
+                ps->skip = 1; ps->init = (d.init ? 1 : 0) | fresh; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
             }
             if (d.init && tid < NU) {
                 const int i = Ush[tid];
@@ -543,7 +595,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
             SM[scur ^ 1][p] = sv;
         } else if (tid == 128) {
-            ps->skip = 0; ps->init = d.init ? 1 : 0; ps->c = c; ps->id = d.id;
+            ps->skip = 0; ps->init = (d.init ? 1 : 0) | fresh; ps->c = c; ps->id = d.id;
 #pragma unroll
             for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
 #pragma unroll
@@ -648,9 +700,11 @@ __device__ long long g_panels_clock[2][20];               // debug builds: per r
 template <typename T, int IDX>
 __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX == 32 ? 2 : 4))) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
-                                                     double* __restrict__ Rbuf, const int* __restrict__ posmap,
+                                                     double* __restrict__ Rbuf, double* __restrict__ Vbuf, const int* __restrict__ posmap,
                                                      double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
 {
+    // Vbuf != null: also V_s = H_s R_s (2 x len, slam_library.cpp:279 written as P - K_s (H_s P)), the second factor of the
+    // rank-2m pass (k_tick_rank)
     // posmap != null (overlapped runs): the strips at the NEXT tick's index set are also dropped into the compact arrays
     // KU [J][2][NU], RU [J][5][NU], SU [NU] (state after the round) for the next tick's chain (tick_carry)
     constexpr int NU = kTickNU;
@@ -706,6 +760,8 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         double* const rdump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
         double* const rdst = (live && k == 0) ? Rb + t : rdump;
         const size_t rstep = (live && k == 0) ? (size_t)ld : 0;
+        double* const vdst = (Vbuf && live && k == 0) ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : rdump;
+        const size_t vstep = (Vbuf && live && k == 0) ? (size_t)ld : 0;
         double* const rudump = RU ? RU + (size_t)v.B * kTickJ * 5 * NU + (threadIdx.x & (kTickDump - 1)) : nullptr;
         double* const rudst = pm >= 0 ? RU + (size_t)b * kTickJ * 5 * NU + pm : rudump;
         const size_t rustep = pm >= 0 ? (size_t)NU : 0;
@@ -734,6 +790,12 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                 const size_t rsp = act ? rstep : 0;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
+                if (Vbuf) {                                             // (uniform)  V_s(r, t) = sum_q H_s(r, set[q]) R_s(q, t)
+                    double* const vd = act ? vdst : rdump;
+                    const size_t vsp = act ? vstep : 0;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) vd[(size_t)(st * 2 + r) * vsp] = hp_entry(ps->Hc, rs, r);
+                }
                 if (posmap) {                                           // (uniform)
                     double* const rud = act ? rudst : rudump;
                     const size_t rusp = act ? rustep : 0;
@@ -775,7 +837,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         PCK(1, 0);
         const int l16 = (threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0;
         const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[l16].skip == 0) & 0xffffu;
-        const unsigned initmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[l16].init != 0) & 0xffffu;
+        const unsigned initmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && (pls[l16].init & 1) != 0) & 0xffffu;
         const int c_lane = pls[l16].c;                                  // correction (lane & 15)'s landmark index
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {
@@ -870,8 +932,14 @@ __device__ inline void last_term<double>(double& p, double after, double, double
 template <typename T, int WAVES, int RPL, bool KLDS>
 __global__ __launch_bounds__(64 * WAVES, KLDS ? 1 : 3) void k_tick_apply(View v, int J, const TickStep* __restrict__ plan,
                                                            const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
-                                                           const T* __restrict__ Pin, T* __restrict__ Pout)
+                                                           const T* __restrict__ Pin, T* __restrict__ Pout, int only_if_init)
 {
+    // only_if_init: launched behind k_tick_rank, which leaves the filters whose round holds a first sighting to this kernel
+    if (only_if_init) {
+        unsigned am; bool any_init;
+        round_flags(plan + (size_t)blockIdx.z * kTickJ, J, am, any_init);
+        if (!any_init) return;
+    }
     typedef Pack16<T> vec_t;
     typedef Pack16<double> d2_t;
     constexpr int VEC = 16 / sizeof(T);                   // elements per 16-byte vector
@@ -1073,8 +1141,13 @@ __global__ __launch_bounds__(64 * WAVES, KLDS ? 1 : 3) void k_tick_apply(View v,
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tick_apply_units(View v, int J, const TickStep* __restrict__ plan,
                                                                  const double* __restrict__ Kbuf, const double* __restrict__ Rbuf,
-                                                                 const double* __restrict__ Pin, double* __restrict__ Pout)
+                                                                 const double* __restrict__ Pin, double* __restrict__ Pout, int only_if_init)
 {
+    if (only_if_init) {
+        unsigned am; bool any_init;
+        round_flags(plan + (size_t)blockIdx.z * kTickJ, J, am, any_init);
+        if (!any_init) return;
+    }
     typedef Pack16<double> d2_t;
     constexpr int ROWS = 128, CW = 16, UW = 8;
     const int b = blockIdx.z;

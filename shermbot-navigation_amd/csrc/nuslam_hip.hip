@@ -88,10 +88,18 @@ struct nuslam_batch {
     int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
+    double* tk_V = nullptr;    // V_s = H_s R_s strips [B][kTickJ][2][ld]: the second factor of the rank-2m pass (ekf_rank.h)
+    // the pass over P of a tick pipeline (nuslam_batch_set_pass_variant): 0 = rank-2m on the matrix cores, the exact chain
+    // for rounds with a first sighting; 1 = always the exact chain, plain kernel; 2 = always the exact chain, two-unit
+    // kernel where it applies; 10 + k = as 0 with tile shape k (experiments)
+    int pass_mode = 0, rank_tile = 0;
+    std::vector<unsigned char> touched;   // [B][n + 1]: landmarks the host can PROVE have been corrected at least once (known-id
+                               // ticks, restore): a round of such ids cannot cancel an INT_MAX diagonal, so the exact-chain
+                               // pass need not be launched behind the rank-2m one
     // unknown association (ekf_da.h): tracked rows / columns / diagonal blocks of P, one launch per correction
     DaBuf da = {};
     void* da_mem = nullptr;
-    int apply_units = 1;       // fp64, one resident generation: the two-unit pass (k_tick_apply_units); 0: k_tick_apply
+    int apply_units = 1;       // exact chain, fp64, one resident generation: the two-unit pass (k_tick_apply_units); 0: k_tick_apply
     unsigned da_round_tag = 0; // resident round kernel: tags of the key slots, kTickJ + 1 per round (slots are never reset)
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
@@ -400,6 +408,8 @@ bool tick_pipeline_pays(const nuslam_batch* h, int m)
     return m >= 4;                                  // (fewer markers: the fixed cost of three launches is not recovered)
 }
 
+int set_rank_attributes();
+
 int ensure_tick_buffers(nuslam_batch* h)
 {
     if (h->tk_plan) return NUSLAM_OK;
@@ -416,6 +426,11 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipMalloc(&h->tk_plan, sizeof(TickStep) * (size_t)h->B * kTickJ));
     HIPCHK(hipMalloc(&h->tk_K, sizeof(double) * ((size_t)h->B * kTickJ * 2 * h->ld + kTickDump)));
     HIPCHK(hipMalloc(&h->tk_R, sizeof(double) * ((size_t)h->B * kTickJ * 5 * h->ld + kTickDump)));
+    HIPCHK(hipMalloc(&h->tk_V, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld));
+    // the rank-2m pass masks the strips of skipped corrections by multiplication: what it reads must always be finite
+    HIPCHK(hipMemsetAsync(h->tk_K, 0, sizeof(double) * ((size_t)h->B * kTickJ * 2 * h->ld + kTickDump), h->stream));
+    HIPCHK(hipMemsetAsync(h->tk_V, 0, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld, h->stream));
+    { int rc = set_rank_attributes(); if (rc) return rc; }
     return NUSLAM_OK;
 }
 
@@ -438,9 +453,60 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
     return o;
 }
 
-// The pass over P of one round from the plan and the strips in tk_K / tk_R
-int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, bool shares_chip = false)
+// ---- the rank-2m pass (ekf_rank.h): tile shapes <RB, CB, WR, WC> per storage type
+template <typename T, int RB, int CB, int WR, int WC>
+int launch_rank_t(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init)
 {
+    typedef RankTile<T, RB, CB, WR, WC> TL;
+    const int tiles_r = (h->ld + TL::WROWS - 1) / TL::WROWS, tiles_c = (h->L + TL::WCOLS - 1) / TL::WCOLS;
+    const bool by_filter = h->B >= 8;                 // a filter per XCD (its strips in one L2), else tile rows per XCD
+    const dim3 grid = by_filter ? dim3((unsigned)(((h->B + 7) / 8) * 8 * tiles_r * tiles_c))
+                                : dim3((unsigned)(((tiles_r + 7) / 8) * 8 * tiles_c), (unsigned)h->B);
+    return launch_lds(h, NUSLAM_K_TICK_RANK, k_tick_rank<T, RB, CB, WR, WC>, grid, dim3(TL::NT), TL::lds_bytes, v, J, plan,
+                      (const double*)h->tk_K, (const double*)h->tk_V, (const T*)h->P(), (T*)h->Palt(), check_init, tiles_r,
+                      tiles_c, by_filter ? 1 : 0);
+}
+#define RANK_TILES(X)                                                                           \
+    X(double, 4, 1, 1, 4) X(double, 1, 4, 4, 1) X(double, 2, 2, 2, 2) X(double, 2, 2, 1, 4)       \
+    X(float, 2, 2, 1, 4) X(float, 1, 4, 4, 1) X(float, 1, 4, 2, 2) X(float, 2, 1, 1, 4)
+int set_rank_attributes()
+{
+#define X(T, RB, CB, WR, WC)                                                                                         \
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_rank<T, RB, CB, WR, WC>),                        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RankTile<T, RB, CB, WR, WC>::lds_bytes));
+    RANK_TILES(X)
+#undef X
+    return NUSLAM_OK;
+}
+int launch_rank(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init)
+{
+    if (h->dtype == NUSLAM_F64) {
+        switch (h->rank_tile) {
+        case 1: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init);
+        case 2: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init);
+        case 3: return launch_rank_t<double, 2, 2, 1, 4>(h, v, J, plan, check_init);
+        default: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init);
+        }
+    }
+    switch (h->rank_tile) {
+    case 1: return launch_rank_t<float, 1, 4, 4, 1>(h, v, J, plan, check_init);
+    case 2: return launch_rank_t<float, 1, 4, 2, 2>(h, v, J, plan, check_init);
+    case 3: return launch_rank_t<float, 2, 1, 1, 4>(h, v, J, plan, check_init);
+    default: return launch_rank_t<float, 2, 2, 1, 4>(h, v, J, plan, check_init);
+    }
+}
+
+// The pass over P of one round from the plan and the strips in tk_K / tk_R / tk_V.  may_init: the host cannot rule out a
+// first sighting in this round (it can for known ids at or below its proven lower bound of `seen`): then the rank-2m pass
+// checks the plan's flags per filter and the exact chain is launched behind it for the filters it left.
+int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, bool shares_chip, bool may_init)
+{
+    int only_if_init = 0;
+    if (h->pass_mode == 0) {
+        int rc = launch_rank(h, v, J, plan, may_init ? 1 : 0);
+        if (rc || !may_init) return rc;
+        only_if_init = 1;
+    }
     const int vec = 16 / (int)h->esize();                      // rows per lane: 16 bytes' worth
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
     const int waves = sweep_waves(h, vec, strips);
@@ -456,42 +522,72 @@ int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, boo
         if (waves == 8 && h->apply_units && !shares_chip)
             rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply_units<8>, grid, block,
                             sizeof(double) * (size_t)J * (5 * 128 + 8 * 5 * 8), v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
         else if (waves == 8)
             rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
         else
             rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2, false>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt());
+                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
     } else {
         if (waves == 8)
             rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
+                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt(), only_if_init);
         else
             rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt());
+                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt(), only_if_init);
     }
     return rc;
+}
+
+// Known-id markers of one tick of filter b, in order: can one of them be the FIRST correction of its landmark (the one that
+// cancels the INT_MAX diagonal; rounds holding one go through the exact chain)?  Decided against what the host can prove:
+// a landmark counts as corrected once a known-id marker for it has certainly reached update() -- resolve(): 1 <= id <= n,
+// the marker loop not broken, id <= total_landmarks (above it the marker is either a first sighting or the `break`,
+// slam.cpp:295-316, which the host cannot tell apart: it then stops marking for the rest of the tick).
+bool tick_may_init(nuslam_batch* h, int b, const int* ids, int m, int total)
+{
+    unsigned char* tb = h->touched.data() + (size_t)b * (h->n + 1);
+    bool may = false, maybe_brk = false;
+    for (int i = 0; i < m; ++i) {
+        const int id = ids[i];
+        if (id < 1 || id > h->n) continue;                 // skipped marker / bad id: nothing is applied
+        if (!tb[id]) may = true;
+        if (maybe_brk) continue;
+        if (id > total) { maybe_brk = true; continue; }
+        tb[id] = 1;
+    }
+    return may;
+}
+// the same for every filter of the handle: one id list for all (host_ids) or filter b's at pf_ids + b * pf_stride
+bool tick_may_init_all(nuslam_batch* h, const int* host_ids, const int* pf_ids, long long pf_stride, int m, int total)
+{
+    if (!host_ids && !pf_ids) return true;
+    bool may = false;
+    for (int b = 0; b < h->B; ++b)
+        may = tick_may_init(h, b, host_ids ? host_ids : pf_ids + (size_t)b * pf_stride, m, total) || may;
+    return may;
 }
 
 // strips + the pass over P of one round, on the handle's stream, from `plan`
 // `between`, if given, is enqueued between the strips and the pass (overlapped runs: the signal for the next chain)
 template <typename F>
-int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan, bool compact, F between)
+int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, const TickStep* plan, bool compact, bool may_init, F between)
 {
     int rc = NUSLAM_OK;
+    double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;       // the rank-2m pass's second factor, formed beside R
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
                                        h->tk_KU, h->tk_RU, h->tk_SU)));
     else
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, h->B), dim3(512),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
                                        h->tk_KU, h->tk_RU, h->tk_SU)));
     if (rc) return rc;
     rc = between();
     if (rc) return rc;
-    return launch_pass(h, v, o.J, plan, compact);
+    return launch_pass(h, v, o.J, plan, compact, may_init);
 }
 
 int ensure_da_buffers(nuslam_batch* h)
@@ -549,7 +645,12 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
                 if (rc) return rc;
             }
         }
-        rc = launch_pass(h, v, o.J, h->tk_plan);
+        if (h->pass_mode == 0) {                                // the association kernels emit R; V = H R for the rank-2m pass
+            rc = launch(h, -1, k_tick_vstrips, dim3((h->L + 255) / 256, h->B), dim3(256), v, o.J, (const TickStep*)h->tk_plan,
+                        (const double*)h->tk_R, h->tk_V);
+            if (rc) return rc;
+        }
+        rc = launch_pass(h, v, o.J, h->tk_plan, false, true);  // (association decides on the device whether a landmark is new)
         if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
@@ -561,9 +662,10 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
 // The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
 // k_tick_panels (the O(len) strips, one quad per state index), k_tick_apply (the one pass over P).
 int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
-                   const double* host_my)
+                   const double* host_my, const int* pf_ids, long long pf_stride)
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);   // (`seen` is cached per TICK, not per round)
     for (int i0 = 0; i0 < m; i0 += kTickJ) {
         const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my);
         View v = h->view();
@@ -571,7 +673,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
                                    (const T*)h->P(), h->tk_plan, TickCarry{}, (int*)nullptr, (int*)nullptr)));
         if (rc) return rc;
-        rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, [] { return (int)NUSLAM_OK; });
+        rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, may_init, [] { return (int)NUSLAM_OK; });
         if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
@@ -591,7 +693,7 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     // filter: then the caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does
     // not move.  host_ids: one id list for all filters; pf_ids: filter b's list at pf_ids + b * pf_stride.
     if (known && tick_pipeline_pays(h, m) && !h->deferred && m > 0) {
-        rc = do_tick_rounds(h, base, m, total, host_ids, host_mx, host_my);
+        rc = do_tick_rounds(h, base, m, total, host_ids, host_mx, host_my, pf_ids, pf_stride);
         if (rc) return rc;
         h->host_seen_valid = false;                 // (the mirror only serves the per-correction path's pairing)
         return NUSLAM_OK;
@@ -662,7 +764,9 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
 // (tick_signal / tick_wait):
 //   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> signal -> pass(t)         (P, state vector)
 //   chain stream      [strips(t-1)] chain(t) -> [strips(t)] chain(t+1) -> ...                 (a 35 x 35 block)
-// prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read; strips(t)
+// prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read -- into the
+// block buffer of tick t+1's parity: chain(t+1) reads it at its start, while prep(t+1) (which only its LAST workgroup holds
+// back until chain(t+1) is done) already writes the other one; strips(t)
 // also drops the gain / prior-row strips at that set into compact arrays; chain(t+1) -- one kernel, waiting inside for
 // the signal behind strips(t) -- first replays the round on the block and applies predict(t+1) (tick_carry), then runs
 // its corrections: all while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic, same bits as the one-stream order
@@ -680,7 +784,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * B));
-        HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * B * kTickNU * kTickNU));
+        HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * 2 * B * kTickNU * kTickNU));      // two: by the parity of the tick that reads it
         HIPCHK(hipMalloc(&h->tk_posmap, sizeof(int) * B * h->ld));
         HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * (B * kTickJ * 2 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * (B * kTickJ * 5 * kTickNU + kTickDump)));
@@ -721,6 +825,9 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         if (rc) return rc;
         const TickObs o = obs_of(t);
         const View v = h->view();
+        const bool may_init = tick_may_init_all(h, h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m,
+                                                h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m,
+                                                (long long)h->tr_ticks * h->tr_m, h->tr_m, total);
 
         // ---- chain stream: chain(t): from P for the first tick (behind predict), from the strips of tick t-1 afterwards
         if (t == t_begin) {
@@ -732,10 +839,11 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             // (it waits, inside, for the strips of tick t-1 at this tick's index set: cnt_next counts the signal kernels
             // enqueued behind k_tick_panels)
             TickCarry cy;
-            cy.blk = h->tk_blk; cy.KU = h->tk_KU; cy.RU = h->tk_RU; cy.SU = h->tk_SU;
+            cy.blk = h->tk_blk + (size_t)(t & 1) * B * kTickNU * kTickNU; cy.KU = h->tk_KU; cy.RU = h->tk_RU; cy.SU = h->tk_SU;
             cy.plan_prev = ((t - t_begin) & 1) ? h->tk_plan : h->tk_plan2;
             cy.wait_cnt = cnt_next; cy.wait_target = h->seq_next; cy.timeouts = timeouts;
             cy.Jt = prev_J; cy.tw = twist_of(t);
+            cy.rank = h->pass_mode == 0 ? 1 : 0;
             // Many filters: their chains' workgroups must not sit on the CUs spinning while the strips they wait for still
             // need room to run -- a one-wave kernel does the waiting for them (their own wait then falls through).
             if ((long long)h->B * 4 > h->n_cu) {
@@ -751,11 +859,12 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), the signal, the pass over P
         if (more)
             DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 2, h->B), dim3(64), v, o, obs_of(t + 1),
-                                       (const T*)h->P(), h->tk_posmap, h->tk_blk, (const int*)cnt_chain, h->seq_chain, timeouts)));
+                                       (const T*)h->P(), h->tk_posmap, h->tk_blk + (size_t)((t + 1) & 1) * B * kTickNU * kTickNU,
+                                       (const int*)cnt_chain, h->seq_chain, timeouts)));
         else
             rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts);
         if (rc) return rc;
-        rc = launch_strips_and_pass(h, v, o, plan, more, [&]() -> int {
+        rc = launch_strips_and_pass(h, v, o, plan, more, may_init, [&]() -> int {
             if (!more) return NUSLAM_OK;
             h->seq_next += 1;                       // the strips at the next tick's index set are complete: chain(t+1) may start
             return launch(h, -1, k_tick_signal, dim3(1), dim3(64), cnt_next);
@@ -776,7 +885,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -804,6 +913,7 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
     if (!h) return NUSLAM_E_NOMEM;
     h->device = device; h->B = B; h->n = n; h->L = 3 + 2 * n; h->ld = roundup(h->L, 32); h->dtype = dtype;
     h->p_stride = (long long)h->ld * h->L;
+    h->touched.assign((size_t)B * (n + 1), 0);
     int rc = [&]() -> int {
         HIPCHK(hipSetDevice(device));
         HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -860,6 +970,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     HIPCHK(hipStreamSynchronize(h->stream));
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
     h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
+    h->touched.assign((size_t)h->B * (h->n + 1), 0);
     return NUSLAM_OK;
 }
 
@@ -949,6 +1060,10 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
+    for (int id = 1; id <= h->n; ++id) {                   // which landmarks still carry INT_MAX: the diagonal says
+        const size_t c = 3 + 2 * (size_t)(id - 1);
+        h->touched[(size_t)b * (h->n + 1) + id] = cov[c + c * (size_t)ld] < 1.0e9 ? 1 : 0;
+    }
     if (h->B == 1) { h->host_seen[0] = seen; h->host_seen_valid = true; }
     else if (h->host_seen_valid) h->host_seen[b] = seen;
     return NUSLAM_OK;
@@ -1427,8 +1542,11 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
 {
-    if (!h || variant < 0 || variant > 1) return NUSLAM_E_ARG;
-    h->apply_units = variant == 0;
+    if (!h || variant < 0 || (variant > 2 && variant < 10) || variant > 13) return NUSLAM_E_ARG;
+    if (variant >= 10) { h->pass_mode = 0; h->rank_tile = variant - 10; return NUSLAM_OK; }
+    h->pass_mode = variant;
+    h->rank_tile = 0;
+    h->apply_units = variant != 1;
     return NUSLAM_OK;
 }
 
@@ -1518,6 +1636,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
     d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode;
+    d->touched = s->touched; d->pass_mode = s->pass_mode; d->rank_tile = s->rank_tile; d->apply_units = s->apply_units;
     rc = [&]() -> int {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipStreamSynchronize(s->stream));

@@ -16,7 +16,9 @@ LIB_PATH = os.environ.get("NUSLAM_HIP_LIB") or os.path.join(PKG_DIR, "libnuslam_
 OK, E_ARG, E_BOUNDS, E_SINGULAR, E_HIP, E_NODEV, E_NOMEM, E_CAPACITY, E_COMM, E_SYNC = range(10)
 COMM_ID_BYTES = 128
 F64, F32 = 0, 1
-K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2, K_TICK_CHAIN, K_TICK_PANELS, K_TICK_APPLY, K_TICK_NEXT, K_DA_BEGIN, K_DA_STEP = range(13)
+K_PREDICT, K_ASSOCIATE, K_UPDATE, K_DENSE_GEMM, K_UPDATE_DEFERRED, K_FLUSH, K_UPDATE2, K_TICK_CHAIN, K_TICK_PANELS, K_TICK_APPLY, K_TICK_NEXT, K_DA_BEGIN, K_DA_STEP, K_TICK_RANK = range(14)
+# nuslam_batch_set_pass_variant: rank-2m pass on the matrix cores (default) / exact chain, plain kernel / exact chain, two-unit kernel
+PASS_RANK, PASS_EXACT_PLAIN, PASS_EXACT = 0, 1, 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -94,12 +96,12 @@ class SimParams(C.Structure):
     nuturtle_description/config/diff_params.yaml of the reference."""
     _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
                                           "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range",
-                                          "lidar", "lidar_min_range", "lidar_max_range")]
+                                          "lidar", "lidar_min_range", "lidar_max_range", "fov", "min_range")]
 
     def __init__(self, **kw):
         d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
                  tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0,
-                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0)
+                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0, fov=0.0, min_range=0.0)
         d.update(kw)
         super().__init__(**d)
 

@@ -58,9 +58,23 @@ class Trace:
         return r, b
 
 
+MIN_RANGE_DEFAULT = 0.2   # m: nearer landmarks are not reported in the well-posed traces
+FOV_DEFAULT = 2.0    # rad: half-angle of the synthetic sensor's field of view in the well-posed traces (see make_trace)
+
+
 def make_trace(n, ticks, m, seed=12345, dL=0.30, dR=0.36, straight_every=25, noise_sigma=None,
-               landmarks=None):
-    """Known-association trace: each tick observes the m landmarks nearest to the true pose."""
+               landmarks=None, fov=None, min_range=0.0):
+    """Known-association trace: each tick observes the m landmarks nearest to the true pose.
+
+    fov (rad): only landmarks whose true bearing lies within +-fov are visible (the m nearest of those).  The reference's
+    update() subtracts the two bearings without wrapping the difference (slam_library.cpp:272): a landmark behind the
+    robot, measured at +pi - e and predicted at -pi + e, yields an innovation of ~2 pi and throws the pose estimate by a
+    radian -- on an all-around trace (fov=None) that happens in nearly every tick, the reference filter itself never
+    tracks the truth, and the sign of such a wrap is a discontinuity that amplifies a one-ulp difference to O(1) within
+    ~50 ticks.  A limited field of view keeps every bearing clear of the +-pi cut and the reference algorithm in its
+    working regime; parity at depth (tests/test_gpu_depth.py) and the bench run on such traces.  min_range (with fov):
+    landmarks nearer than this are not reported either -- at 5 cm the 3 cm marker noise alone can carry a bearing across
+    the cut."""
     rng = np.random.default_rng(seed + 1)
     lm = make_landmarks(n, seed) if landmarks is None else np.asarray(landmarks, dtype=np.float64)
     m = min(m, n)
@@ -92,14 +106,36 @@ def make_trace(n, ticks, m, seed=12345, dL=0.30, dR=0.36, straight_every=25, noi
         tw[t] = (dth, dx, 0.0)
         truth[t] = (th, x, y)
         d = lm - np.array([x, y])
-        near = np.argsort(d[:, 0] ** 2 + d[:, 1] ** 2, kind="stable")[:m]
         c, s = np.cos(th), np.sin(th)
+        d2 = d[:, 0] ** 2 + d[:, 1] ** 2
+        if fov is not None:
+            bearing = np.arctan2(-s * d[:, 0] + c * d[:, 1], c * d[:, 0] + s * d[:, 1])
+            d2 = np.where((np.abs(bearing) <= fov) & (d2 >= min_range * min_range), d2, np.inf)
+            assert np.isfinite(d2).sum() >= m, "fewer than m landmarks inside the field of view"
+        near = np.argsort(d2, kind="stable")[:m]
         bx = c * d[near, 0] + s * d[near, 1]
         by = -s * d[near, 0] + c * d[near, 1]
         mx[t] = bx + rng.normal(0.0, sigma, size=m)
         my[t] = by + rng.normal(0.0, sigma, size=m)
         ids[t] = near + 1
     return Trace(lm, thL, thR, tw, mx, my, ids, truth)
+
+
+def make_wellposed_trace(n, ticks, m, **kw):
+    """make_trace on which the reference algorithm itself is well-conditioned, so that two correct implementations stay
+    together for hundreds of ticks (the oracle against itself with one input moved by one ulp: 1e-9 at tick 200, where
+    the plain trace has lost all digits by tick 50 -- tests/test_trace_conditioning.py):
+      * a +-FOV_DEFAULT field of view and a minimum range: no bearing near the +-pi cut, whose un-wrapped difference
+        (slam_library.cpp:272) is a 2 pi discontinuity;
+      * wheel increments that are exact binary fractions (5/16, 3/8, straight ticks 11/32): the accumulated wheel angles
+        are exact, so a straight tick has dth == 0.0 exactly and takes the straight branch (slam_library.cpp:77).  With
+        0.30 / 0.36 the accumulated angles round, a 'straight' tick comes out with dth = 4.6e-17, takes the arc branch,
+        and dx/dth * (sin(th + dth) - sin(th)) is 0 or 2.4 cm depending on the last bit of the heading."""
+    kw.setdefault("fov", FOV_DEFAULT)
+    kw.setdefault("min_range", MIN_RANGE_DEFAULT)
+    kw.setdefault("dL", 0.3125)
+    kw.setdefault("dR", 0.375)
+    return make_trace(n, ticks, m, **kw)
 
 
 def warmup_observations(landmarks, pose=(0.0, 0.0, 0.0), seed=12345, noise_sigma=None):

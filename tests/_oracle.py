@@ -43,12 +43,12 @@ class SimParams(C.Structure):
     Defaults: nuturtlesim/config/tube_world_params.yaml + nuturtle_description/config/diff_params.yaml."""
     _fields_ = [(k, C.c_double) for k in ("wheel_base", "wheel_radius", "dt", "twist_noise", "slip_min", "slip_max",
                                           "tube_radius", "robot_radius", "tube_var", "marker_sigma", "max_range",
-                                          "lidar", "lidar_min_range", "lidar_max_range")]
+                                          "lidar", "lidar_min_range", "lidar_max_range", "fov", "min_range")]
 
     def __init__(self, **kw):
         d = dict(wheel_base=0.16, wheel_radius=0.033, dt=1.0 / 50, twist_noise=0.0, slip_min=0.9, slip_max=1.0,
                  tube_radius=0.0381, robot_radius=0.08, tube_var=0.001, marker_sigma=0.0, max_range=1.0,
-                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0)
+                 lidar=0.0, lidar_min_range=0.05, lidar_max_range=1.0, fov=0.0, min_range=0.0)
         d.update(kw)
         super().__init__(**d)
 

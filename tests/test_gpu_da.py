@@ -4,7 +4,10 @@ rows / columns / diagonal blocks go through the same floating-point operations i
 covariance would, so every association verdict (match, new landmark, gray zone), the resolved ids, `seen`, the state
 and the covariance must agree BIT FOR BIT -- from a cold start (every landmark a first sighting), warm, with markers in
 the gray zone, the same landmark twice in a tick, more markers than one round of 16, fp32 storage, batches, and traces
-with empty marker slots.  (Against the oracle the default path is exercised by test_gpu_parity / test_gpu_baseline_sizes.)"""
+with empty marker slots.  (Against the oracle the default path is exercised by test_gpu_parity / test_gpu_baseline_sizes.)
+
+Statements about the EXACT chain (PASS_EXACT): the default pass over P, the rank-2m update on the matrix cores, is the
+same algebra re-associated and is held to a tolerance (tests/test_gpu_rank.py); the verdicts it must still reproduce.""" 
 import numpy as np
 import pytest
 
@@ -25,6 +28,7 @@ def pair_of_filters(hip, n, dtype=0, Qm=Q, pipe=1):
     a = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R, dtype=dtype)
     b = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R, dtype=dtype)
     a.as_batch().set_tick_mode(pipe)
+    a.as_batch().set_pass_variant(hip.PASS_EXACT)
     b.as_batch().set_tick_mode(0)               # k_associate + k_update per marker
     return a, b
 
@@ -119,6 +123,7 @@ def test_da_pipeline_batch_run(hip, pipe, B, n, m, dtype):
     for mode in (pipe, 0):
         bt = hip.Batch(B, n, Q, R, dtype=dtype)
         bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_EXACT)
         bt.load_trace(tw, mx, my, None)
         bt.run(0, T)
         stats.append(bt.status())
@@ -140,6 +145,7 @@ def test_da_pipeline_device_trace_with_empty_marker_slots(hip, pipe):
     for mode in (pipe, 0):
         bt = hip.Batch(B, n, Q, R)
         bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_EXACT)
         bt.simulate(sim, lm, cmd, m, 4321, first_filter=0, known_ids=False)
         bt.run(0, T)
         assert bt.status() == (-1, 0)
@@ -187,6 +193,7 @@ def test_da_pipeline_long_run_n1000(hip):
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
         bt = ekf.as_batch()
         bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_EXACT)
         bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, None, bcast=True)
         for t0 in range(0, T, 500):
             bt.run(t0, t0 + 500)

@@ -3,7 +3,12 @@ the one-pass-per-correction kernel it replaces: the same floating-point operatio
 so state, covariance, `seen`, resolved ids and latched status must agree BIT FOR BIT -- through landmark
 initialisation (INT_MAX diagonal), skipped markers (id < 0), the break of the marker loop (id > total_landmarks), bad
 ids, repeated ids inside one tick, fewer and more markers than one round of 16, fp32 storage and batches with
-per-filter ids.  (Against the oracle the default path is exercised by every other GPU test.)"""
+per-filter ids.  (Against the oracle the default path is exercised by every other GPU test.)
+
+These are statements about the EXACT chain (nuslam_batch_set_pass_variant PASS_EXACT / PASS_EXACT_PLAIN); the default pass,
+the rank-2m update on the matrix cores, is the same algebra re-associated and is held to a tolerance instead
+(tests/test_gpu_rank.py, tests/test_gpu_depth.py) -- except that the two stream orders of a run must agree bit for bit
+for EVERY pass variant (test_overlapped_run_is_bit_identical).""" 
 import numpy as np
 import pytest
 
@@ -18,6 +23,7 @@ def pair_of_filters(hip, n, dtype=0):
     a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
     b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
     a.as_batch().set_tick_mode(1)
+    a.as_batch().set_pass_variant(hip.PASS_EXACT)
     bb = b.as_batch()
     bb.set_tick_mode(0)
     bb.set_pairing(False)                       # one k_update launch per correction: the reference arithmetic
@@ -72,6 +78,7 @@ def test_tick_pipeline_batch_with_per_filter_ids(hip):
     for mode in (1, 0):
         bt = hip.Batch(B, n, Q, R)
         bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_EXACT)
         if mode == 0:
             bt.set_pairing(False)
         bt.load_trace(tw, mx, my, ids)
@@ -99,6 +106,7 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
         g.restore(o.state.copy(), o.cov.copy(), o.seen)
         bt = g.as_batch()
         bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_EXACT)
         bt.set_pairing(pairing)
         fs.append(g)
     for t in range(T):
@@ -115,10 +123,12 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
     assert es < 1e-6 and ep < 1e-6
 
 
+@pytest.mark.parametrize("variant", ["rank", "exact", "exact_plain"])
 @pytest.mark.parametrize("B,n,m,dtype,cold", [(1, 40, 16, 0, False), (3, 30, 5, 0, False), (4, 20, 16, 1, False), (2, 12, 8, 0, True),
                                                 (96, 10, 6, 0, True),      # (more chains than a quarter of the CUs: a one-wave kernel waits for them)
+                                                (1, 12, 3, 0, False),      # (a small filter, few markers: the hand-offs' margins are a few us)
                                                 (1, 1000, 16, 0, False)])  # BASELINE configs[1] size: the bench's default path
-def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold):
+def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold, variant):
     """nuslam_batch_run with the chain of tick t+1 running ahead on its own stream (it forms its starting block from
     tick t's strips itself: tick_carry) against the one-stream order: same state, covariance, seen, status -- warm, through first
     sightings (cold), with skipped markers and a straight tick (dth == 0) in the trace, fp64 and fp32 storage."""
@@ -133,6 +143,7 @@ def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold):
     for overlap in (True, False):
         bt = hip.Batch(B, n, Q, R, dtype=dtype)
         bt.set_tick_mode(1)
+        bt.set_pass_variant({"rank": hip.PASS_RANK, "exact": hip.PASS_EXACT, "exact_plain": hip.PASS_EXACT_PLAIN}[variant])
         bt.set_overlap(overlap)
         if not cold:
             bx, by, wid = synth.warmup_observations(traces[0].landmarks)
