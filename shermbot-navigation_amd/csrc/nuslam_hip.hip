@@ -480,19 +480,21 @@ int set_rank_attributes()
 }
 int launch_rank(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init)
 {
+    // tile 0 is the measured best per storage type (profiles/r03/pass_tiles.txt); 1..3 stay selectable for measurement
+    // (nuslam_batch_set_pass_variant(10 + k)) -- every tile computes the same bits
     if (h->dtype == NUSLAM_F64) {
         switch (h->rank_tile) {
-        case 1: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init);
-        case 2: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init);
+        case 1: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init);
+        case 2: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init);
         case 3: return launch_rank_t<double, 2, 2, 1, 4>(h, v, J, plan, check_init);
-        default: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init);
+        default: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init);
         }
     }
     switch (h->rank_tile) {
-    case 1: return launch_rank_t<float, 1, 4, 4, 1>(h, v, J, plan, check_init);
-    case 2: return launch_rank_t<float, 1, 4, 2, 2>(h, v, J, plan, check_init);
-    case 3: return launch_rank_t<float, 2, 1, 1, 4>(h, v, J, plan, check_init);
-    default: return launch_rank_t<float, 2, 2, 1, 4>(h, v, J, plan, check_init);
+    case 1: return launch_rank_t<float, 2, 2, 1, 4>(h, v, J, plan, check_init);
+    case 2: return launch_rank_t<float, 1, 4, 4, 1>(h, v, J, plan, check_init);
+    case 3: return launch_rank_t<float, 1, 4, 2, 2>(h, v, J, plan, check_init);
+    default: return launch_rank_t<float, 2, 1, 1, 4>(h, v, J, plan, check_init);
     }
 }
 
