@@ -246,6 +246,9 @@ int nuslam_batch_simulate(nuslam_batch_t* h, const nuslam_sim_params* p, const d
 int nuslam_batch_get_trace(nuslam_batch_t* h, int b, double* tw, double* mx, double* my, int* ids, double* truth);
 /* the simulated lidar scan (360 ranges, robot frame) of filter b at tick t; only after a generation with lidar != 0 */
 int nuslam_batch_get_scan(nuslam_batch_t* h, int b, int tick, float out_ranges[360]);
+/* hook for the device's rigid2d::normalize_angle (rigid2d/src/rigid2d.cpp:9-13; on the device a two-constant range
+ * reduction, csrc/ekf_device.h): out[i] = normalize_angle(in[i]), computed on the device */
+int nuslam_device_normalize_angle(const double* in, int n, double* out, int device);
 /* bit-exact hook for the generator's RNG: the Philox4x32-10 block of (seed, counter), computed on the device */
 int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4], int device);
 

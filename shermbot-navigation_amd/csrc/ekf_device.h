@@ -72,11 +72,32 @@ struct TwistArg {
     double dth0, dx0;
 };
 
-__device__ inline double normalize_angle(double rad)       // rigid2d/src/rigid2d.cpp:9-13
+// rigid2d::normalize_angle, rigid2d/src/rigid2d.cpp:9-13, is atan2(sin(rad), cos(rad)): the representative of rad in
+// (-pi, pi].  Here the same value by range reduction: rad - k 2pi with 2pi as a two-constant sum (hi + lo, fma), the
+// identity for |rad| <= pi.  It agrees with glibc's atan2(sin, cos) to <= 1 ulp -- the class of difference the device's
+// own libm already had -- including the edges (+-pi map to themselves, pi + 1 ulp to -pi, 3 pi to +pi; pinned against the
+// reference-generated vectors of tests/golden/rigid2d_ref.npz by tests/test_gpu_more.py through nuslam_device_normalize_angle),
+// and it takes ~15 instructions where sincos + atan2 take ~450: three of these wraps sat on the serial chain of every
+// correction (the heading after K nu, :276; the two of z_hat, :20 and :157).  Beyond 1e6 rad, where k 2pi_lo loses bits,
+// the libm form is kept.
+__device__ inline double normalize_angle(double rad)
 {
-    double sn, cs;
-    sincos(rad, &sn, &cs);          // one argument reduction for both (same values as sin(rad), cos(rad))
-    return atan2(sn, cs);
+    constexpr double kPi = 3.141592653589793, kTwoPiHi = 6.283185307179586, kTwoPiLo = 2.4492935982947064e-16;
+    constexpr double kInvTwoPi = 0.15915494309189535;
+    const double a = fabs(rad);
+    if (a <= kPi) return rad;
+    if (!(a <= 1.0e6)) {
+        double sn, cs;
+        sincos(rad, &sn, &cs);
+        return atan2(sn, cs);
+    }
+    const double k = rint(rad * kInvTwoPi);
+    double r = fma(-k, kTwoPiHi, rad);
+    r = fma(-k, kTwoPiLo, r);
+    // k was rounded from a rounded quotient: r may sit one period off by a hair beyond +-pi
+    if (r > kPi) r = fma(-1.0, kTwoPiLo, r - kTwoPiHi);
+    else if (r < -kPi) r = fma(1.0, kTwoPiLo, r + kTwoPiHi);
+    return r;
 }
 
 __device__ inline void cartesian2polar(double x, double y, double& r, double& b) // slam_library.cpp:16-22

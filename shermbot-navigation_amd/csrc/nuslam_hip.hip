@@ -1254,7 +1254,30 @@ __global__ void k_philox_probe(unsigned c0, unsigned c1, unsigned c2, unsigned c
     for (int q = 0; q < 4; ++q) out[q] = r[q];
 }
 
+__global__ void k_normalize_probe(const double* __restrict__ in, int n, double* __restrict__ out)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t < n) out[t] = normalize_angle(in[t]);
+}
+
 } // namespace
+
+int nuslam_device_normalize_angle(const double* in, int n, double* out, int device)
+{
+    if (!in || !out || n < 1) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    double* d = nullptr;
+    HIPCHK(hipMalloc(&d, 2 * sizeof(double) * (size_t)n));
+    hipError_t e = hipMemcpy(d, in, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_normalize_probe, dim3((n + 63) / 64), dim3(64), 0, 0, (const double*)d, n, d + n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return NUSLAM_OK;
+}
 
 int nuslam_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4], int device)
 {

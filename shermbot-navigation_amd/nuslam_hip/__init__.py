@@ -81,6 +81,7 @@ SYMBOLS = [
     ("nuslam_batch_get_trace", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip, _dp]),
     ("nuslam_batch_get_scan", C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("nuslam_philox4x32_10", C.c_int, [C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.c_int]),
+    ("nuslam_device_normalize_angle", C.c_int, [_dp, C.c_int, _dp, C.c_int]),
     ("nuslam_build_info", C.c_char_p, []),
     ("nuslam_ekf_snapshot", C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _ip]),
     ("nuslam_comm_unique_id", C.c_int, [C.POINTER(C.c_ubyte)]),
@@ -111,6 +112,14 @@ def map_to_odom(odom_xyth, state3):
     out = np.zeros(3)
     _chk(lib().nuslam_map_to_odom(_p(np.ascontiguousarray(odom_xyth, dtype=np.float64)),
                                   _p(np.ascontiguousarray(state3, dtype=np.float64)), _p(out)), "map_to_odom")
+    return out
+
+
+def device_normalize_angle(a, device=0):
+    """rigid2d::normalize_angle as the device evaluates it (csrc/ekf_device.h), elementwise."""
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    out = np.zeros_like(a)
+    _chk(lib().nuslam_device_normalize_angle(_p(a), a.size, _p(out), device), "device_normalize_angle")
     return out
 
 

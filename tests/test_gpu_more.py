@@ -270,3 +270,33 @@ def test_batch_equals_single_at_config4_size(hip):
     bt.run(0, T)
     for b in (0, B - 1):
         assert np.array_equal(bt.state(b), g.state) and np.array_equal(bt.cov(b), g.cov)
+
+
+def test_device_normalize_angle_matches_the_reference(hip):
+    """rigid2d::normalize_angle on the device is a two-constant range reduction, not atan2(sin, cos) (csrc/ekf_device.h):
+    it must give the reference's values -- the reference-generated vectors of tests/golden/rigid2d_ref.npz (the compiled
+    rigid2d.cpp) and glibc's atan2(sin, cos) -- to <= 2 ulp, the edges included: +-pi, one ulp either side of them, 3 pi,
+    -7.5, multiples of 2 pi, tiny and zero arguments, 25 000 random angles, and beyond 1e6 rad (libm form kept there)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "rigid2d_ref.npz"))
+    pi = np.pi
+    edge = np.array([pi, -pi, np.nextafter(pi, 4.0), np.nextafter(pi, 0.0), np.nextafter(-pi, -4.0), np.nextafter(-pi, 0.0),
+                     3 * pi, -3 * pi, -7.5, 7.5, 2 * pi, -2 * pi, 4 * pi, 6.0, -6.0, 100.0, -100.0, 1e-300, 0.0, -0.0, 5 * pi,
+                     999999.0, 1.0e6, 1234567.0, -9.87654321e8])
+    rng = np.random.default_rng(11)
+    rnd = np.concatenate([rng.uniform(-2 * pi, 2 * pi, 20000), rng.uniform(-40, 40, 5000)])
+
+    def ulps(x, ref):
+        d = np.abs(x - ref)
+        return np.where(d == 0, 0.0, d / np.spacing(np.maximum(np.abs(x), np.abs(ref))))
+
+    got = hip.device_normalize_angle(g["ang"])
+    u_gold = ulps(got, g["norm"]).max()
+    for a in (edge, rnd):
+        ref = np.arctan2(np.sin(a), np.cos(a))
+        got = hip.device_normalize_angle(a)
+        assert ulps(got, ref).max() <= 2.0, (a[ulps(got, ref).argmax()], got[ulps(got, ref).argmax()], ref[ulps(got, ref).argmax()])
+    e = hip.device_normalize_angle(edge[:6])
+    assert e[0] == pi and e[1] == -pi                     # +-pi (the fp64 values lie inside (-pi, pi]) map to themselves
+    assert abs(e[2] + pi) < 1e-15 and abs(e[4] - pi) < 1e-15      # one ulp beyond: the other end
+    print("device normalize_angle vs the compiled reference's vectors: %.1f ulp worst" % u_gold)
+    assert u_gold <= 2.0
