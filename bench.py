@@ -80,6 +80,10 @@ def parse():
                     help="nuslam_batch_set_pass_variant: 0 (default) the rank-2m pass on the matrix cores, 1 / 2 the exact chain "
                          "(plain / two-unit kernel), 10 + k the rank-2m pass with tile shape k")
     ap.add_argument("--plain-pass", action="store_true", help="nuslam_batch_set_pass_variant(1): the exact chain, plain kernel")
+    ap.add_argument("--dense-random-f", action="store_true",
+                    help="ekf5000: propagate with a fixed dense random Jacobian instead of the reference's A = I + B formed on the "
+                         "device every tick -- a GEMM micro-measurement on fully dense operands (MFMA loops on mostly-zero "
+                         "operands hold a higher clock), not the reference's predict")
     ap.add_argument("--parity-ticks", type=int, default=40, help="ticks of the same-run parity leg (through nuslam_batch_run)")
     ap.add_argument("--no-api", action="store_true", help="skip the api_driven leg (the C++ class driven call by call)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
@@ -370,7 +374,7 @@ def main():
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
         ekf.sync()
         warm_state = (ekf.state, ekf.cov, ekf.seen) if (rank == 0 and world == 1 and args.cpu_seconds > 0 and args.workload == "ekf1000") else None   # cpu_baseline: N=1 only
-        if args.workload == "ekf5000":
+        if args.workload == "ekf5000" and args.dense_random_f:
             # a DENSE Jacobian kept resident in HBM: the reference's A = I + B for the first twist plus a small dense
             # random perturbation -- every operand non-zero, because MFMA loops on mostly-zero operands hold a higher
             # clock and would flatter the number (cdna_hip_programming.md section 5.4 rule 25)
@@ -383,6 +387,10 @@ def main():
             ekf.restore(s0, P0, sn)
             ekf.use_dense_predict(True)
             del F, P0
+        elif args.workload == "ekf5000":
+            # configs[2] as the reference runs it: every predict forms A = I + B(theta', twist) on the device
+            # (slam_library.cpp:127-148) and propagates the covariance with it through the two dense MFMA products (:104)
+            ekf.use_dense_predict(2)
     else:
         bt = nh.Batch(B, n, Q, R, dtype=dtype, device=dev)
         # initialise every filter's map with one resident warm-up tick of n observations
@@ -538,7 +546,9 @@ def main():
         "config": {"workload": {"ekf1000": "single EKF per GPU, known association (BASELINE configs[1])",
                                 "batch": "batch of independent EKFs sharded over the GPUs (BASELINE configs[3])",
                                 "da1000": "single EKF per GPU, unknown data association (BASELINE configs[4])",
-                                "ekf5000": "single EKF per GPU, fp32, dense MFMA F P F^T predict (BASELINE configs[2])"}[args.workload],
+                                "ekf5000": "single EKF per GPU, fp32, dense MFMA F P F^T predict (BASELINE configs[2]); F = "
+                                           + ("a fixed dense random Jacobian (GEMM micro-measurement)" if args.dense_random_f else
+                                              "the reference's A = I + B(theta', twist), formed on the device every tick")}[args.workload],
                    "landmarks": n, "state_len": L, "filters_rank0": B, "filters_total": filters_total,
                    "filters_counted_by_reduction": n_filters_seen,
                    "updates_per_step": m, "parallelism": "replicas x%d" % world if args.workload != "batch" else "filters sharded x%d" % world,

@@ -88,10 +88,15 @@ int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy);
  * P <- F P F^T + Qbar, two len^3 products on the matrix cores (MFMA).  F is host memory, len x len,
  * column-major, leading dimension ldf.  The state is not touched. */
 int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf);
-/* F stays resident in HBM after the call above; F == NULL there re-uses the resident Jacobian.  With
- * nuslam_ekf_use_dense_predict(h, 1) every later predict of this filter (nuslam_ekf_predict, _tick, nuslam_batch_run)
- * advances the state as slam_library.cpp:71-94 and propagates the covariance with the resident dense Jacobian on
- * the matrix cores instead of the two-non-zero shortcut (BASELINE config "MFMA F P F^T path enabled"). */
+/* F stays resident in HBM after the call above; F == NULL there re-uses the resident Jacobian.
+ * nuslam_ekf_use_dense_predict(h, 2): every later predict of this filter (nuslam_ekf_predict, _tick, nuslam_batch_run)
+ * IS the reference's predict on the matrix cores (BASELINE config "MFMA F P F^T path enabled"): the state advances as
+ * slam_library.cpp:71-94, A = I + B of getA (:127-148, evaluated at the advanced heading) is kept resident -- the device
+ * rewrites its two non-zeros of B from this tick's twist -- and the covariance becomes A P A^T + Qbar as two dense len^3
+ * products (:104), not the two-non-zero shortcut.  For fp64 storage the result is bit-identical to the shortcut (the f64
+ * MFMA is a k-ordered fma chain and the extra terms are exact zeros).
+ * enable == 1: as 2 but with whatever Jacobian the last nuslam_ekf_predict_dense staged, unchanged from tick to tick (a
+ * GEMM measurement, not the reference's predict); 0: back to the shortcut. */
 int nuslam_ekf_use_dense_predict(nuslam_ekf_t* h, int enable);
 /* ExtendedKalman::update(const Twist2D&, colvec z, int id), slam_library.cpp:263-282 (the twist is unused there). */
 int nuslam_ekf_update(nuslam_ekf_t* h, double range, double bearing, int id);

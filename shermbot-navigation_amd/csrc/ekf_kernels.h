@@ -79,12 +79,25 @@ __global__ __launch_bounds__(256) void k_init(View v, const double* __restrict__
     if (t < 2) v.akey[2 * b + t] = kNoKey;
 }
 
+// A = I (len x len, leading dimension ld, padding rows zero) for the dense-Jacobian predict that forms getA on the device
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_identity(int L, int ld, T* __restrict__ F)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)ld * L) return;
+    const int i = (int)(e % ld), j = (int)(e / ld);
+    F[e] = (i == j) ? (T)1 : (T)0;
+}
+
 // ------------------------------------------------------------------------------------------------ predict
 // STATE_ONLY: predictEstimate + the tick bookkeeping only; the covariance is then propagated by the dense MFMA
 // path (nuslam_ekf_predict_dense) instead of the two-non-zero shortcut below.
 template <typename T, bool STATE_ONLY>
-__global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restrict__ P, int bookkeeping)
+__global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restrict__ P, int bookkeeping, T* __restrict__ Fa)
 {
+    // Fa (STATE_ONLY, may be null): the resident dense Jacobian of filter 0, already I everywhere else: getA's two entries
+    // A(1,0), A(2,0) (slam_library.cpp:133-146, at the heading AFTER predictEstimate) are written into it here, so that the
+    // two MFMA products that follow compute the reference's A P A^T with this tick's A
     // bookkeeping == 0: the control words are carried by the chain stream (overlapped runs), this kernel leaves them alone
     const int b = blockIdx.z;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
     if (t < v.ld) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
 
     if (STATE_ONLY) {
+        if (t == 0 && Fa && b == 0) { Fa[1] = (T)a1; Fa[2] = (T)a2; }
         if (t == 0 && bookkeeping) {
             const int* ci = v.c_in + b * C_WORDS;
             int* co = v.c_out + b * C_WORDS;

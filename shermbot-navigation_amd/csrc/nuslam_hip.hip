@@ -121,6 +121,7 @@ struct nuslam_batch {
     double* dU = nullptr; double* dV = nullptr;
     int J = 0;
     bool dense_predict = false;   // do_predict: state-only kernel + the two MFMA products with the staged Jacobian
+    bool dense_getA = false;      // ... and the staged Jacobian is getA(tw) itself: I + B, B(1,0), B(2,0) rewritten every predict
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[NUSLAM_K_COUNT];
@@ -257,10 +258,12 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
     dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
     int rc = NUSLAM_OK;
     if (h->dense_predict) {
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, true>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping)));
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, true>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping,
+                                   (T*)(h->dense_getA ? h->wF : nullptr))));
         if (!rc) rc = launch_dense(h);
     } else {
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping)));
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, v, tw, (T*)h->P(), h->predict_bookkeeping,
+                                   (T*)nullptr)));
     }
     if (rc) return rc;
     h->sidx ^= 1;
@@ -1818,15 +1821,33 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
                                hipMemcpyHostToDevice));
         }
         c->f_staged = true;
+        c->dense_getA = false;                   // the resident matrix is the caller's again
     }
     return launch_dense(c);
 }
 
 int nuslam_ekf_use_dense_predict(nuslam_ekf_t* h, int enable)
 {
-    if (!h) return NUSLAM_E_ARG;
-    if (enable && !h->core->f_staged) return NUSLAM_E_ARG;
-    h->core->dense_predict = enable != 0;
+    if (!h || enable < 0 || enable > 2) return NUSLAM_E_ARG;
+    nuslam_batch* c = h->core;
+    if (enable == 2) {
+        // the reference's own predict on the matrix cores: A = I + B resident in HBM, its two non-zeros of B rewritten by
+        // every predict from (theta', twist) on the device (k_predict), then P <- A P A^T + Qbar as two dense products
+        HIPCHK(hipSetDevice(c->device));
+        const size_t elems = (size_t)c->p_stride;
+        if (!c->wF) HIPCHK(hipMalloc(&c->wF, c->esize() * elems));
+        int rc = NUSLAM_OK;
+        DISPATCH_T(c, rc = launch(c, -1, k_fill_identity<T>, dim3((unsigned)((elems + 255) / 256)), dim3(256), c->L, c->ld, (T*)c->wF));
+        if (rc) return rc;
+        c->f_staged = true;
+        c->dense_getA = true;
+        c->dense_predict = true;
+        return NUSLAM_OK;
+    }
+    if (enable && !c->f_staged) return NUSLAM_E_ARG;
+    if (enable && c->dense_getA) return NUSLAM_E_ARG;        // the resident matrix is getA's now: stage a caller's F again first
+    c->dense_predict = enable != 0;
+    if (!enable) c->dense_getA = false;
     return NUSLAM_OK;
 }
 

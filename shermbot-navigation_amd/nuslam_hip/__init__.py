@@ -484,7 +484,9 @@ class EKF:
         _chk(lib().nuslam_ekf_set_deferred(self._h, 1 if enable else 0), "ekf_set_deferred")
 
     def use_dense_predict(self, enable=True):
-        _chk(lib().nuslam_ekf_use_dense_predict(self._h, 1 if enable else 0), "ekf_use_dense_predict")
+        """2: the reference's predict on the matrix cores (getA formed on the device every tick); True / 1: the Jacobian
+        last staged by predict_dense, unchanged; False / 0: the O(len) shortcut."""
+        _chk(lib().nuslam_ekf_use_dense_predict(self._h, int(enable)), "ekf_use_dense_predict")
 
     def update(self, r, phi, idx):
         _chk(lib().nuslam_ekf_update(self._h, r, phi, idx), "ekf_update")

@@ -300,3 +300,25 @@ def test_device_normalize_angle_matches_the_reference(hip):
     assert abs(e[2] + pi) < 1e-15 and abs(e[4] - pi) < 1e-15      # one ulp beyond: the other end
     print("device normalize_angle vs the compiled reference's vectors: %.1f ulp worst" % u_gold)
     assert u_gold <= 2.0
+
+
+def test_dense_predict_with_device_jacobian_is_the_reference_predict_fp64(hip):
+    """nuslam_ekf_use_dense_predict(h, 2): A = I + B(theta', twist) (slam_library.cpp:127-148) is formed on the device
+    every tick and P <- A P A^T + Qbar runs as two dense products on the matrix cores.  fp64: bit-identical to the
+    O(len) shortcut k_predict (both are the dense product's k-ordered sums, the extra terms exact zeros), over a
+    trajectory with corrections in between, a straight tick (dth == 0) included."""
+    n, m, T = 50, 8, 6
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, T, m, landmarks=lm, straight_every=3, dL=0.3125, dR=0.375)
+    bx, by, wid = synth.warmup_observations(lm)
+    fs = []
+    for dense in (2, 0):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+        g.as_batch().set_pass_variant(hip.PASS_EXACT)
+        g.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+        g.use_dense_predict(dense)
+        for t in range(T):
+            g.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t], want_ids=False)
+        assert g.status() == 0
+        fs.append((g.state, g.cov))
+    assert np.array_equal(fs[0][0], fs[1][0]) and np.array_equal(fs[0][1], fs[1][1])
