@@ -195,7 +195,12 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
 /* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable > 0 lets the serial chain of tick t+1 run on a
  * second stream while the strips and the pass over P of tick t run on the handle's (the host knows the next tick's
  * markers from the resident trace; the streams hand over through device counters, every wait bounded).  Same bits
- * either way.  enable < 0 (default): on for a handle of one filter, off for batches (measured). */
+ * either way.  Before its first overlapped run a handle PROBES whether the two streams really execute side by side (a
+ * profiler's counter pass or a serialising environment makes them take turns, and every hand-off would expire): if not,
+ * its runs take the one-stream path -- same bits, no dependency between streams.  enable == 2: test hook, as 1 but the
+ * "second stream" is the handle's own, so the probe must find them serialised.  enable < 0 (default): off with the
+ * rank-2m pass (one stream is the faster order there), on for one filter / off for batches with the exact chain.
+ * Should a hand-off expire all the same (NUSLAM_E_SYNC), the handle refuses further ticks until it is restored. */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
 /* How a tick pipeline's ONE pass over the covariance applies the round's corrections.
  *   0 (default)  as a rank-2m update on the matrix cores: update()'s P <- (I - K H) P (slam_library.cpp:279) re-associated

@@ -126,12 +126,12 @@ __device__ inline void tick_signal(int* cnt)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline bool tick_wait(const int* cnt, int target)      // every thread of the workgroup calls it
+__device__ inline bool tick_wait(const int* cnt, int target, int iters = 1 << 18)      // every thread of the workgroup calls it
 {
     __shared__ int ok_sh;
     if (threadIdx.x == 0) {
         int ok = 0;
-        for (int it = 0; it < (1 << 18); ++it) {
+        for (int it = 0; it < iters; ++it) {
             if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target >= 0) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(4);
         }
@@ -147,9 +147,9 @@ __device__ inline bool tick_wait(const int* cnt, int target)      // every threa
 // counter has arrived, and starts with the usual kernel-boundary acquire.  (The wait used to sit at the top of
 // k_tick_panels: the mere presence of the agent-scope fence in that kernel, never executed in one-stream runs, took it
 // from 20 to 37 us.)
-__global__ __launch_bounds__(64) void k_tick_wait(const int* __restrict__ cnt, int target, int* __restrict__ timeouts)
+__global__ __launch_bounds__(64) void k_tick_wait(const int* __restrict__ cnt, int target, int* __restrict__ timeouts, int iters)
 {
-    if (!tick_wait(cnt, target) && threadIdx.x == 0) atomicAdd(timeouts, 1);
+    if (!tick_wait(cnt, target, iters) && threadIdx.x == 0) atomicAdd(timeouts, 1);
 }
 // ... and the producer side as one: everything the kernels in front of it on its stream stored is published
 __global__ __launch_bounds__(64) void k_tick_signal(int* __restrict__ cnt)

@@ -45,6 +45,7 @@ thread_local std::string g_hip_err;
     } while (0)
 
 constexpr int kSweepCW = 16;  // columns per wave in the sweep
+constexpr int kNotConcurrent = -1000;   // run_overlapped -> nuslam_batch_run: the two streams do not run side by side here
 
 inline int roundup(int x, int m) { return (x + m - 1) / m * m; }
 
@@ -104,8 +105,14 @@ struct nuslam_batch {
     // cross-tick overlap (nuslam_batch_run on a resident trace): the chain of tick t+1 runs on its own stream while
     // strips and pass of tick t run on the handle's
     int predict_bookkeeping = 1;   // 0 while an overlapped run carries the control words on the chain stream
-    int overlap = -1;          // 1 / 0: nuslam_batch_set_overlap; -1: on for a single filter (96.6 vs 105.5 us per tick at N = 1000),
-                               // off for batches, whose pass fills every CU and only delays the chain (6.9M vs 7.2M updates/s)
+    int overlap = -1;          // 1 / 0: nuslam_batch_set_overlap; -1: off with the rank-2m pass (on one stream a tick at N = 1000 takes
+                               // 77.7 us against 82.1 overlapped: the pass left the critical path's price range); with the exact chain
+                               // on for a single filter, off for batches, whose pass fills every CU and only delays the chain
+    bool ov_same_stream = false;   // test hook (set_overlap(2)): the chain "stream" IS the handle's, nothing can run beside it
+    int ov_ok = -1;            // -1: not probed; 1: the two streams were seen running side by side; 0: they were not (a tool or
+                               // environment serialises dispatches): overlapped runs then take the one-stream path
+    bool poisoned = false;     // a bounded device-side wait expired (NUSLAM_E_SYNC read back): state / covariance are not to be
+                               // trusted; ticks are refused until restore() or a re-initialisation
     hipStream_t stream2 = nullptr;
     TickStep* tk_plan2 = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
     int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
@@ -252,6 +259,9 @@ int launch_dense(nuslam_batch* c)
 
 int do_predict(nuslam_batch* h, const TwistArg& tw)
 {
+    if (h->poisoned) return NUSLAM_E_SYNC;
+    h->last_tick = -1;                    // (nuslam_batch_run sets it again behind its ticks: the truth-dependent statistics
+                                          // only ever refer to a tick of the resident trace that was really the last one applied)
     int frc = flush_pending(h);
     if (frc) return frc;
     View v = h->view();
@@ -310,6 +320,7 @@ int sweep_waves(const nuslam_batch* h, int vec, int strips)
 
 int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
 {
+    if (h->poisoned) return NUSLAM_E_SYNC;
     if (h->deferred && mode != MODE_DA) {
         if (h->J == kMaxPending) { int frc = flush_pending(h); if (frc) return frc; }
         View vd = h->view();
@@ -784,7 +795,8 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         // its own hardware queue, served first: a chain is one workgroup per filter
         int prio_lo = 0, prio_hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
+        if (h->ov_same_stream) h->stream2 = h->stream;
+        else HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * B * kTickJ));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
@@ -794,11 +806,27 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * (B * kTickJ * 2 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * (B * kTickJ * 5 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_SU, sizeof(double) * B * kTickNU));
-        HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 4));
-        HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 4, h->stream));
+        HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 8));
+        HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
         HIPCHK(hipEventCreateWithFlags(&h->ov_start, hipEventDisableTiming));
         h->seq_chain = h->seq_next = 0;
     }
+    if (h->ov_ok < 0) {
+        // Do the two streams really run side by side here?  (Under rocprofv3 --pmc, a serialising debug environment or a CU
+        // mask they do not, and every hand-off of the run would expire.)  One probe per handle: a one-wave consumer on the
+        // chain stream waits -- briefly -- for a counter that a one-wave producer, enqueued AFTER it on the handle's stream,
+        // bumps.  If it gives up, overlapped runs of this handle take the one-stream path: same bits, no dependency.
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int rcp = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)(h->tk_sync + 3), 1, h->tk_sync + 4, 1 << 13);
+        if (!rcp) rcp = launch(h, -1, k_tick_signal, dim3(1), dim3(64), h->tk_sync + 3);
+        if (rcp) return rcp;
+        HIPCHK(hipStreamSynchronize(h->stream2));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        int gave_up = 0;
+        HIPCHK(hipMemcpy(&gave_up, h->tk_sync + 4, sizeof(int), hipMemcpyDeviceToHost));
+        h->ov_ok = gave_up ? 0 : 1;
+    }
+    if (!h->ov_ok) return kNotConcurrent;             // (internal: the caller falls back to the one-stream loop)
     HIPCHK(hipMemsetAsync(h->tk_posmap, 0xff, sizeof(int) * B * h->ld, h->stream));      // every index: not in the next tick's set
     auto obs_of = [&](int t) {
         ObsArg o;
@@ -852,7 +880,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             // Many filters: their chains' workgroups must not sit on the CUs spinning while the strips they wait for still
             // need room to run -- a one-wave kernel does the waiting for them (their own wait then falls through).
             if ((long long)h->B * 4 > h->n_cu) {
-                rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts);
+                rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts, 1 << 18);
                 if (rc) return rc;
             }
             DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256),
@@ -867,7 +895,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
                                        (const T*)h->P(), h->tk_posmap, h->tk_blk + (size_t)((t + 1) & 1) * B * kTickNU * kTickNU,
                                        (const int*)cnt_chain, h->seq_chain, timeouts)));
         else
-            rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts);
+            rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts, 1 << 18);
         if (rc) return rc;
         rc = launch_strips_and_pass(h, v, o, plan, more, may_init, [&]() -> int {
             if (!more) return NUSLAM_OK;
@@ -899,7 +927,7 @@ void free_batch(nuslam_batch* h)
     for (auto e : h->pool) (void)hipEventDestroy(e);
     for (auto e : h->ov_events) (void)hipEventDestroy(e);
     if (h->ov_start) (void)hipEventDestroy(h->ov_start);
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->stream2 && h->stream2 != h->stream) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -976,6 +1004,8 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
     h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
     h->touched.assign((size_t)h->B * (h->n + 1), 0);
+    h->poisoned = false;
+    h->last_tick = -1;
     return NUSLAM_OK;
 }
 
@@ -993,6 +1023,7 @@ int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
         HIPCHK(hipMemcpy(&expired, h->tk_sync + 2, sizeof(int), hipMemcpyDeviceToHost));
         if (expired) {
             if (!st) { st = NUSLAM_E_SYNC; bad = 0; }
+            h->poisoned = true;                    // the run went on from a hand-off that never arrived: nothing after it is valid
             if (clear) HIPCHK(hipMemset(h->tk_sync + 2, 0, sizeof(int)));
         }
     }
@@ -1000,6 +1031,7 @@ int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
         for (int b = 0; b < h->B; ++b) c[(size_t)b * C_WORDS + C_STATUS] = 0;
         HIPCHK(hipMemcpy(h->ctrl[h->cidx], c.data(), sizeof(int) * c.size(), hipMemcpyHostToDevice));
     }
+    if (st == NUSLAM_E_SYNC) h->poisoned = true;     // (the resident association round latches its expired waits in the status word)
     if (first_bad) *first_bad = bad;
     if (status_out) *status_out = st;
     return NUSLAM_OK;
@@ -1065,6 +1097,8 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
+    h->poisoned = false;                                   // (a restored filter is a valid one again)
+    h->last_tick = -1;
     for (int id = 1; id <= h->n; ++id) {                   // which landmarks still carry INT_MAX: the diagonal says
         const size_t c = 3 + 2 * (size_t)(id - 1);
         h->touched[(size_t)b * (h->n + 1) + id] = cov[c + c * (size_t)ld] < 1.0e9 ? 1 : 0;
@@ -1434,12 +1468,17 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
     int* saved_log = h->id_log;
     h->id_log = nullptr;  // resident traces do not log resolved ids
     int rc = NUSLAM_OK;
+    if (h->poisoned) { h->id_log = saved_log; return NUSLAM_E_SYNC; }
     const bool known_trace = h->tr_ids != nullptr && !h->tr_presence_only;
-    if ((h->overlap < 0 ? h->B == 1 : h->overlap != 0) && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
-        (h->tick_mode != 0) && (h->tr_bcast ? !h->h_ids.empty() : true)) {     // (auto: with the chains overlapped the pipeline pays for one filter too)
+    const bool want_overlap = h->overlap < 0 ? (h->B == 1 && h->pass_mode != 0) : h->overlap != 0;
+    if (want_overlap && h->ov_ok != 0 && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
+        (h->tick_mode != 0) && (h->tr_bcast ? !h->h_ids.empty() : true)) {
         rc = run_overlapped(h, t_begin, t_end, total_landmarks);
-        h->id_log = saved_log;
-        return rc;
+        if (rc != kNotConcurrent) {              // (else: the probe found the streams serialised -> the loop below)
+            h->id_log = saved_log;
+            return rc;
+        }
+        rc = NUSLAM_OK;
     }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
@@ -1580,8 +1619,10 @@ int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
 
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable)
 {
-    if (!h) return NUSLAM_E_ARG;
+    if (!h || enable > 2) return NUSLAM_E_ARG;
+    if (enable == 2 && h->stream2 && h->stream2 != h->stream) return NUSLAM_E_ARG;     // (the hook must be set before the first overlapped run)
     h->overlap = enable < 0 ? -1 : (enable != 0);
+    if (enable == 2) h->ov_same_stream = true;
     return NUSLAM_OK;
 }
 

@@ -406,7 +406,9 @@ class Batch:
         _chk(lib().nuslam_batch_set_tick_mode(self._h, int(mode)), "batch_set_tick_mode")
 
     def set_overlap(self, enable=True):
-        _chk(lib().nuslam_batch_set_overlap(self._h, -1 if enable is None else (1 if enable else 0)), "batch_set_overlap")
+        """True / False / None (library default); 2: the test hook (second stream = the handle's own)."""
+        _chk(lib().nuslam_batch_set_overlap(self._h, -1 if enable is None else (2 if enable == 2 and enable is not True else (1 if enable else 0))),
+             "batch_set_overlap")
 
     def set_pass_variant(self, variant):
         _chk(lib().nuslam_batch_set_pass_variant(self._h, int(variant)), "batch_set_pass_variant")

@@ -161,3 +161,29 @@ def test_overlapped_run_is_bit_identical(hip, B, n, m, dtype, cold, variant):
         assert np.array_equal(res[0][k][0], res[1][k][0]), "state of filter %d" % k
         assert np.array_equal(res[0][k][1], res[1][k][1]), "covariance of filter %d" % k
         assert res[0][k][2] == res[1][k][2]
+
+
+@pytest.mark.parametrize("variant", ["rank", "exact"])
+def test_overlapped_run_falls_back_when_the_streams_do_not_run_side_by_side(hip, variant):
+    """Overlap robustness: with the chain "stream" forced to be the handle's own (set_overlap(2)) nothing can run beside the
+    handle's kernels -- what a profiler's counter pass or a serialising environment does to two real streams.  The
+    handle's probe must notice, the run must take the one-stream order, and state / covariance / status must equal the
+    one-stream run bit for bit (no NUSLAM_E_SYNC, no poisoned handle)."""
+    n, m, T = 40, 16, 7
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, T, m, landmarks=lm, straight_every=3, dL=0.3125, dR=0.375)
+    bx, by, wid = synth.warmup_observations(lm)
+    res = []
+    for overlap in (2, False):
+        bt = hip.Batch(1, n, Q, R)
+        bt.set_tick_mode(1)
+        bt.set_pass_variant(hip.PASS_RANK if variant == "rank" else hip.PASS_EXACT)
+        bt.set_overlap(overlap)
+        bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+        bt.run(0, 1)
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+        bt.run(0, 4)
+        bt.run(4, T)
+        assert bt.status() == (-1, 0)
+        res.append((bt.state(0), bt.cov(0), bt.seen(0)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
