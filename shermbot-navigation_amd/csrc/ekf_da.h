@@ -525,20 +525,7 @@ __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int 
 constexpr int kStatusSync = 9;      // NUSLAM_E_SYNC
 constexpr int kDaRoundLds = (kTickJ * 5 + kTickJ * 2 + kTickJ * 5) * kDaSlots * (int)sizeof(double);
 
-#ifdef NUSLAM_DA_EXP_PLAIN
-__device__ inline void st_agent(double* p, double x) { *p = x; }
-#else
-__device__ inline void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#endif
-__device__ inline void st_agent(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ inline double ld_agent(const double* p)
-{
-    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline long long ld_agent(const long long* p)
-{
-    return __hip_atomic_load(const_cast<long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (st_agent / ld_agent: ekf_tick.h)
 
 #ifdef NUSLAM_DA_CLOCK
 __device__ long long g_da_clock[4][16];       // debug builds (make daclock): per wave of workgroup 0, 100 MHz ticks per phase

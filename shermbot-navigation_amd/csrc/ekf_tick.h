@@ -85,6 +85,29 @@ struct TickCarry {
     TwistArg tw;               // this tick's twist
 };
 
+// Agent-scope (sc1) stores and loads: what one workgroup hands to workgroups on other CUs / XCDs INSIDE a launch travels as
+// these on both sides (MI355X_MICROARCH.md, "Valid forms": 8-byte agent atomics both sides, the signal after every storing
+// wave's vmcnt(0) and a workgroup barrier) -- no fences, whose L2 write-back / L1 invalidate cost ~1.7 us each.
+#ifdef NUSLAM_DA_EXP_PLAIN
+__device__ inline void st_agent(double* p, double x) { *p = x; }
+#else
+__device__ inline void st_agent(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+__device__ inline void st_agent(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_agent(const double* p)
+{
+    return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline long long ld_agent(const long long* p)
+{
+    return __hip_atomic_load(const_cast<long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline int ld_agent(const int* p)
+{
+    return __hip_atomic_load(const_cast<int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
 // (__syncthreads() also drains vmcnt, i.e. waits ~1 us for the acknowledgement of every plan store in flight).
 __device__ inline void lds_barrier()
@@ -346,13 +369,32 @@ __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz
 // FUSED: the workgroup first waits for the previous tick's strips, replays that tick's corrections on the 35 x 35 block
 // (what used to be a kernel of its own, k_tick_next: ~5 us of launch and one more hand-off per tick on the critical path
 // of the run) and applies this tick's predict to it (tick_carry), then runs the chain.
-template <typename T, bool FUSED>
-__global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
-                                                    TickStep* __restrict__ plan, TickCarry cy,
-                                                    int* __restrict__ ctrl_out4, int* __restrict__ done_cnt)
+// PUBLISH (k_tick_front): the strips are formed by workgroups of the SAME launch, correction by correction, while the chain
+// runs on: every plan entry is stored with agent-scope stores and announced through *pub_flag = pub_base + (entries
+// complete) -- one correction late, at a point where the storing waves' vmcnt(0) waits are free (their stores are >1 us old).
+struct TickPublish {
+    int* flag;             // per filter: pub_base + number of complete plan entries of this round
+    int base;
+};
+__device__ inline void plan_store(bool publish, double* p, double x)
+{
+    if (publish) st_agent(p, x);
+    else *p = x;
+}
+__device__ inline void plan_store_head(bool publish, TickStep* ps, int skip, int init, int c, int id)
+{
+    if (publish) {                                                      // (four ints = two 8-byte words)
+        st_agent(reinterpret_cast<long long*>(&ps->skip), (long long)(unsigned)skip | ((long long)init << 32));
+        st_agent(reinterpret_cast<long long*>(&ps->c), (long long)(unsigned)c | ((long long)id << 32));
+    } else { ps->skip = skip; ps->init = init; ps->c = c; ps->id = id; }
+}
+
+template <typename T, bool FUSED, bool PUBLISH>
+__device__ inline void tick_chain(const int b, View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+                                  TickStep* __restrict__ plan, TickCarry cy,
+                                  int* __restrict__ ctrl_out4, int* __restrict__ done_cnt, TickPublish pub)
 {
     constexpr int NU = kTickNU;
-    const int b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ld = v.ld;
@@ -452,7 +494,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         TickStep* ps = pl + st;
         if (tid == 0 && v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = d.id;
         if (d.skip) {
-            if (tid == 0) { ps->skip = 1; ps->init = 0; ps->c = 3; ps->id = d.id; }
+            if (tid == 0) plan_store_head(PUBLISH, ps, 1, 0, 3, d.id);
             continue;
         }
         const int pos = 3 + 2 * st, c = d.c;
@@ -463,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             // A first sighting needs the wrapped heading before anything else (initializeLandmark, :255-261): serial path
             if (wave == 0 && theta_raw) {
                 const double th = normalize_angle(SM[scur][0]);
-                if (lane == 0) { SM[scur][0] = th; pl[last_live].MP[0][7] = th; }
+                if (lane == 0) { SM[scur][0] = th; plan_store(PUBLISH, &pl[last_live].MP[0][7], th); }
             }
             if (pend) run_pending(BK[bcur], BK[bcur ^ 1], MPl[mb], pend_pos, wave == 0 ? -1 : tid - 64);
             lds_barrier();
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         // (wave 2) | the deferred block update (waves 0, 2, 3)
         if (wave == 0 && theta_raw) {
             const double th = normalize_angle(SM[scur][0]);
-            if (lane == 0) { SM[scur][0] = th; pl[last_live].MP[0][7] = th; }   // the heading row after that correction (:276)
+            if (lane == 0) { SM[scur][0] = th; plan_store(PUBLISH, &pl[last_live].MP[0][7], th); }   // the heading row after that correction (:276)
         }
         if (wave == 1 || wave == 2) {
             const double x = S0[1], y = S0[2];
@@ -531,6 +573,9 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             }
         }
         theta_raw = false;
+        // (PUBLISH: wave 0's stores of the previous entry -- its rows of M a correction ago, the wrapped heading at the top of
+        // this phase -- are waited for here, where this wave would wait for the head wave anyway)
+        if (PUBLISH && wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CK(0);
         lds_barrier();
         CK(1);
@@ -559,14 +604,21 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
             double (*Mn)[8] = MPl[mb ^ 1];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; ps->MP[p][q] = m[q]; }
+            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; plan_store(PUBLISH, &ps->MP[p][q], m[q]); }
             Mn[p][5] = bef; Mn[p][6] = aft;
-            ps->MP[p][5] = bef; ps->MP[p][6] = aft;
-            if (p > 0) ps->MP[p][7] = 0.0;                              // (MP[0][7]: the wrapped heading, written when it is formed)
-        } else if (!sing && tid >= 128 && tid < 128 + NU) {             // the five prior rows at the columns of U
-            const int p = tid - 128;
+            if (!PUBLISH) {                                             // (the strip workgroups of k_tick_front form the two flags themselves)
+                ps->MP[p][5] = bef; ps->MP[p][6] = aft;
+                if (p > 0) ps->MP[p][7] = 0.0;                          // (MP[0][7]: the wrapped heading, written when it is formed)
+            }
+        } else if (wave == 2) {
+            // (PUBLISH: this wave's stores of the PREVIOUS entry -- its scalars, a phase and a head ago -- have long landed:
+            // the wait is free here, and after the barrier below entry st - 1 may be announced)
+            if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!sing && tid < 128 + NU) {                              // the five prior rows at the columns of U
+                const int p = tid - 128;
 #pragma unroll
-            for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
+                for (int q = 0; q < 5; ++q) plan_store(PUBLISH, &ps->BR[p][q], B0[sp[q]][p]);
+            }
         }
         CK(2);
         lds_barrier();
@@ -574,7 +626,8 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         if (sing) {                                                     // singular S: update() throws after the init
             if (status == 0) status = kStatusSingular;
             if (tid == 0) {
-                ps->skip = 1; ps->init = (d.init ? 1 : 0) | fresh; ps->c = c; ps->id = d.id; ps->lxy[0] = lx; ps->lxy[1] = ly;
+                plan_store_head(PUBLISH, ps, 1, (d.init ? 1 : 0) | fresh, c, d.id);
+                plan_store(PUBLISH, &ps->lxy[0], lx); plan_store(PUBLISH, &ps->lxy[1], ly);
             }
             if (d.init && tid < NU) {
                 const int i = Ush[tid];
@@ -594,13 +647,31 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
             acc = fma(KP[1], dz1, acc);
             sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
             SM[scur ^ 1][p] = sv;
-        } else if (tid == 128) {
-            ps->skip = 0; ps->init = (d.init ? 1 : 0) | fresh; ps->c = c; ps->id = d.id;
+        } else if (PUBLISH && wave == 2) {
+            // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4], dz[2],
+            // lxy[2], contiguous behind them (a single lane storing twenty agent-scope words one after the other cost 0.4 us)
+            const int w = lane;
+            if (w < 20) {
+                long long word;
+                if (w == 0) word = (long long)(unsigned)0 | ((long long)((d.init ? 1 : 0) | fresh) << 32);
+                else if (w == 1) word = (long long)(unsigned)c | ((long long)d.id << 32);
+                else {
+                    const int f = w - 2;                                // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz = hd[16], hd[17]; 16, 17: lxy = hd[14], hd[15]
+                    word = __double_as_longlong(hd[f < 14 ? f : (f < 16 ? f + 2 : f - 2)]);
+                }
+                st_agent(reinterpret_cast<long long*>(ps) + w, word);
+            }
+        } else if (!PUBLISH && tid == 128) {
+            plan_store_head(false, ps, 0, (d.init ? 1 : 0) | fresh, c, d.id);
 #pragma unroll
             for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
 #pragma unroll
             for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
             ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
+        } else if (PUBLISH && tid == 192) {
+            // entries 0 .. st-1 are complete: wave 0 waited for its stores at the end of phase 1, wave 2 at the top of phase
+            // 2, both in front of the barrier just passed
+            st_agent(pub.flag + b, pub.base + st);
         }
         CK(4);
         lds_barrier();
@@ -618,7 +689,12 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
 #endif
     if (theta_raw && wave == 0) {                                       // the heading after the last correction
         const double th = normalize_angle(SM[scur][0]);
-        if (lane == 0) pl[last_live].MP[0][7] = th;
+        if (lane == 0) plan_store(PUBLISH, &pl[last_live].MP[0][7], th);
+    }
+    if (PUBLISH) {                                                      // the whole round is complete
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) st_agent(pub.flag + b, pub.base + J);
     }
     if (tid == 0) {
         int* co = v.c_out + b * C_WORDS;
@@ -629,6 +705,14 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
         __syncthreads();
         if (tid == 0) tick_signal(done_cnt);
     }
+}
+
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+                                                    TickStep* __restrict__ plan, TickCarry cy,
+                                                    int* __restrict__ ctrl_out4, int* __restrict__ done_cnt)
+{
+    tick_chain<T, FUSED, false>(blockIdx.x, v, o, total_landmarks, P, plan, cy, ctrl_out4, done_cnt, TickPublish{ nullptr, 0 });
 }
 
 // ------------------------------------------------------------------------------------------------ overlapped runs: prep
@@ -899,6 +983,170 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         if (live && k == 0) v.s_out[(size_t)b * ld + t] = sv;
         if (pm >= 0) SU[(size_t)b * NU + pm] = sv;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ chain and strips in one launch
+// One filter (or few): the strips need nothing of correction s but plan entry s, and a correction of the chain takes ~2.2 us
+// where the strips' share of it takes ~0.6.  k_tick_front runs the chain on workgroup 0 and the strip workgroups BESIDE it
+// in the same launch: they pick each plan entry up as the chain announces it (TickPublish; agent-scope stores and loads,
+// no fences) and have the round's K / R / V strips and the new state ready ~one correction after the chain ends, instead of
+// 17 us (N = 1000) after it as a kernel of their own.  The whole grid is resident at once (the host launches this form
+// only while 1 + the strip workgroups fit the chip), the chain is block 0 -- dispatched first --, every wait is bounded
+// and an expired one is reported through `timeouts` (NUSLAM_E_SYNC).  Same arithmetic as k_tick_panels<T, 32>, entry by
+// entry: same bits.
+constexpr int kPlanWords = (int)(sizeof(TickStep) / 8);
+
+template <typename T>
+__device__ inline void tick_panels_stream(const int b, const int wg, View v, TickObs o, const T* __restrict__ P,
+                                          const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
+                                          double* __restrict__ Rbuf, double* __restrict__ Vbuf, TickPublish pub,
+                                          int* __restrict__ timeouts)
+{
+    constexpr int NU = kTickNU, IDX = 32;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (IDX * 4));
+    const int k = threadIdx.x & 3;
+    const int t = wg * IDX + ((threadIdx.x % (IDX * 4)) >> 2);
+    const int ld = v.ld, L = v.L;
+    const T* Pb = P + (size_t)b * v.p_stride;
+    const int J = o.J;
+    double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
+    double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
+    __shared__ long long slot[kPlanWords];                              // the plan entry in flight
+    __shared__ int ok_sh;
+    const TickStep* ps = reinterpret_cast<const TickStep*>(slot);
+
+    int Uk[kQuadRows];
+#pragma unroll
+    for (int j = 0; j < kQuadRows; ++j) {
+        const int p = 4 * j + k;
+        int u = 3;
+        if (p < 3) u = p;
+        else if (p < NU) {
+            const int st = (p - 3) >> 1;
+            int id = 0;
+            if (st < J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+            u = ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((p - 3) & 1);
+        }
+        Uk[j] = u;
+    }
+    // this lane's panel entries and where its strips go (role 0: column t of the row panel, R and V; role 1: row t of the
+    // column panel, K, the state entry)
+    const bool live = role == 0 ? t < L : t < ld;
+    const int tr = live ? t : 0;
+    const bool owner = live && k == 0;
+    double* const dump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
+    double PN[kQuadRows];
+#pragma unroll
+    for (int j = 0; j < kQuadRows; ++j)
+        PN[j] = role == 0 ? (double)Pb[(size_t)tr * ld + Uk[j]] : (double)Pb[(size_t)Uk[j] * ld + tr];
+    double sv = role == 1 ? v.s_in[(size_t)b * ld + tr] : 0.0;
+    const long long* src = reinterpret_cast<const long long*>(plan + (size_t)b * kTickJ);
+    bool failed = false;
+
+#pragma unroll
+    for (int st = 0; st < kTickJ; ++st) {
+        if (st < J && !failed) {                                        // (uniform)
+            // ---- wait for entry st, fetch it (every load of the handed-off bytes is an agent-scope load)
+            if (threadIdx.x == 0) {
+                int ok = 0;
+                for (int it = 0; it < (1 << 18); ++it) {
+                    if (ld_agent(pub.flag + b) - (pub.base + st + 1) >= 0) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                ok_sh = ok;
+            }
+            __syncthreads();
+            if (!ok_sh) {
+                failed = true;
+                if (threadIdx.x == 0) atomicAdd(timeouts, 1);
+            } else {
+                const long long* e = src + (size_t)st * kPlanWords;
+                for (int w = threadIdx.x; w < kPlanWords; w += 256) slot[w] = ld_agent(e + w);
+                __syncthreads();
+                const bool act = ps->skip == 0;
+                const bool init = (ps->init & 1) != 0;
+                const int c = ps->c;
+                const int pos = 3 + 2 * st;
+                if (role == 0) {
+                    if (act) {
+                        const double rs[5] = { quad_bcast(PN[0], 0), quad_bcast(PN[0], 1), quad_bcast(PN[0], 2),
+                                               quad_bcast(PN[pos >> 2], pos & 3), quad_bcast(PN[(pos + 1) >> 2], (pos + 1) & 3) };
+                        double* const rd = owner ? Rb + t : dump;
+                        const size_t rsp = owner ? (size_t)ld : 0;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
+                        if (Vbuf) {
+                            double* const vd = owner ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : dump;
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) vd[(size_t)(st * 2 + r) * rsp] = hp_entry(ps->Hc, rs, r);
+                        }
+#pragma unroll
+                        for (int j = 0; j < kQuadRows; ++j) {
+                            if (4 * j >= 3 && 4 * j + 3 < pos + 2) continue;
+                            const int p = 4 * j + k;
+                            const bool on = p < NU && !(p >= 3 && p < pos + 2);
+                            const int pc = on ? p : 0;
+                            const double m[5] = { ps->MP[pc][0], ps->MP[pc][1], ps->MP[pc][2], ps->MP[pc][3], ps->MP[pc][4] };
+                            const int iu = Uk[j];                       // the row of P this entry lives in
+                            const double nv = p1_entry<T>(m, rs, PN[j], (iu > 2 && iu < c) ? 1.0 : 0.0, (iu > c + 1) ? 1.0 : 0.0);
+                            PN[j] = on ? nv : PN[j];
+                        }
+                    }
+                } else {
+                    if (!act && init) {                                 // the landmark was initialised before update() threw
+                        if (t == c) sv = ps->lxy[0];
+                        if (t == c + 1) sv = ps->lxy[1];
+                    }
+                    if (act) {
+                        const int setv[5] = { 0, 1, 2, c, c + 1 };
+                        const double pc[5] = { quad_bcast(PN[0], 0), quad_bcast(PN[0], 1), quad_bcast(PN[0], 2),
+                                               quad_bcast(PN[pos >> 2], pos & 3), quad_bcast(PN[(pos + 1) >> 2], (pos + 1) & 3) };
+                        double Hc[10], Si[4], K[2], m[5];
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
+                        gain_row(pc, Hc, Si, t, setv, K, m);
+                        double* const kd = owner ? Kb + t : dump;
+                        const size_t ksp = owner ? (size_t)ld : 0;
+                        kd[(size_t)(st * 2 + 0) * ksp] = K[0];
+                        kd[(size_t)(st * 2 + 1) * ksp] = K[1];
+                        const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
+                        double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;
+                        double acc = 0.0;
+                        acc = fma(K[0], ps->dz[0], acc);
+                        acc = fma(K[1], ps->dz[1], acc);
+                        s0 = s0 + acc;                                  // :275
+                        if (t == 0) s0 = ps->MP[0][7];                  // :276, wrapped by the chain
+                        sv = s0;
+#pragma unroll
+                        for (int j = 0; j < kQuadRows; ++j) {
+                            if (4 * j >= 3 && 4 * j + 3 < pos + 2) continue;
+                            const int p = 4 * j + k;
+                            const bool on = p < NU && !(p >= 3 && p < pos + 2);
+                            const int pcx = on ? p : 0;
+                            const double r[5] = { ps->BR[pcx][0], ps->BR[pcx][1], ps->BR[pcx][2], ps->BR[pcx][3], ps->BR[pcx][4] };
+                            const double nv = p1_entry<T>(m, r, PN[j], bef, aft);
+                            PN[j] = on ? nv : PN[j];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+                                                    TickStep* __restrict__ plan, double* __restrict__ Kbuf,
+                                                    double* __restrict__ Rbuf, double* __restrict__ Vbuf,
+                                                    int* __restrict__ pub_flag, int pub_base, int* __restrict__ timeouts)
+{
+    const TickPublish pub = { pub_flag, pub_base };
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0) tick_chain<T, false, true>(b, v, o, total_landmarks, P, plan, TickCarry{}, nullptr, nullptr, pub);
+    else tick_panels_stream<T>(b, (int)blockIdx.x - 1, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
 }
 
 // ------------------------------------------------------------------------------------------------ the pass over P

@@ -89,6 +89,9 @@ struct nuslam_batch {
     int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
+    int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
+    int seq_pub = 0;
+    int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
     double* tk_V = nullptr;    // V_s = H_s R_s strips [B][kTickJ][2][ld]: the second factor of the rank-2m pass (ekf_rank.h)
     // the pass over P of a tick pipeline (nuslam_batch_set_pass_variant): 0 = rank-2m on the matrix cores, the exact chain
     // for rounds with a first sighting; 1 = always the exact chain, plain kernel; 2 = always the exact chain, two-unit
@@ -445,6 +448,13 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipMemsetAsync(h->tk_K, 0, sizeof(double) * ((size_t)h->B * kTickJ * 2 * h->ld + kTickDump), h->stream));
     HIPCHK(hipMemsetAsync(h->tk_V, 0, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld, h->stream));
     { int rc = set_rank_attributes(); if (rc) return rc; }
+    HIPCHK(hipMalloc(&h->tk_pub, sizeof(int) * (size_t)h->B));
+    HIPCHK(hipMemsetAsync(h->tk_pub, 0, sizeof(int) * (size_t)h->B, h->stream));
+    if (!h->tk_sync) {                             // {chain, next} completion counters, expired waits, probe words
+        HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 8));
+        HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
+    }
+    h->seq_pub = 0;
     return NUSLAM_OK;
 }
 
@@ -686,11 +696,23 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my);
         View v = h->view();
         int rc = NUSLAM_OK;
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
-                                   (const T*)h->P(), h->tk_plan, TickCarry{}, (int*)nullptr, (int*)nullptr)));
-        if (rc) return rc;
-        rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, may_init, [] { return (int)NUSLAM_OK; });
-        if (rc) return rc;
+        const int strip_wgs = (h->ld + 31) / 32;
+        if (h->front && (long long)(1 + strip_wgs) * h->B <= h->n_cu) {
+            // chain and strips in ONE launch: the strip workgroups follow the chain entry by entry (k_tick_front)
+            double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + strip_wgs, h->B), dim3(256), v, o, total,
+                                       (const T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, h->tk_pub, h->seq_pub, h->tk_sync + 2)));
+            if (rc) return rc;
+            h->seq_pub += 2 * kTickJ;
+            rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init);
+            if (rc) return rc;
+        } else {
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
+                                       (const T*)h->P(), h->tk_plan, TickCarry{}, (int*)nullptr, (int*)nullptr)));
+            if (rc) return rc;
+            rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, may_init, [] { return (int)NUSLAM_OK; });
+            if (rc) return rc;
+        }
         h->sidx ^= 1;
         h->cidx ^= 1;
         h->pidx ^= 1;
@@ -806,8 +828,6 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipMalloc(&h->tk_KU, sizeof(double) * (B * kTickJ * 2 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_RU, sizeof(double) * (B * kTickJ * 5 * kTickNU + kTickDump)));
         HIPCHK(hipMalloc(&h->tk_SU, sizeof(double) * B * kTickNU));
-        HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 8));
-        HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
         HIPCHK(hipEventCreateWithFlags(&h->ov_start, hipEventDisableTiming));
         h->seq_chain = h->seq_next = 0;
     }
@@ -918,7 +938,7 @@ void free_batch(nuslam_batch* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1602,8 +1622,9 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
-    if (!h || mode < -1 || mode > 2) return NUSLAM_E_ARG;
-    h->tick_mode = mode;
+    if (!h || mode < -1 || mode > 3) return NUSLAM_E_ARG;
+    h->front = mode != 3;                          // 3: as 1 with the chain and the strips as two launches (measurement)
+    h->tick_mode = mode == 3 ? 1 : mode;
     return NUSLAM_OK;
 }
 

@@ -19,10 +19,12 @@ pytestmark = pytest.mark.gpu
 Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
 
 
-def pair_of_filters(hip, n, dtype=0):
+def pair_of_filters(hip, n, dtype=0, mode=1):
+    """mode 1: the tick pipeline as the library launches it for one filter (chain and strips in ONE launch, k_tick_front);
+    mode 3: chain and strips as two launches (what batches and overlapped runs take)"""
     a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
     b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
-    a.as_batch().set_tick_mode(1)
+    a.as_batch().set_tick_mode(mode)
     a.as_batch().set_pass_variant(hip.PASS_EXACT)
     bb = b.as_batch()
     bb.set_tick_mode(0)
@@ -34,10 +36,11 @@ def same(a, b):
     return np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.seen == b.seen and a.status() == b.status()
 
 
+@pytest.mark.parametrize("mode", [1, 3], ids=["one-launch", "two-launches"])
 @pytest.mark.parametrize("n,m,dtype", [(10, 10, 0), (10, 3, 0), (40, 16, 0), (40, 16, 1), (60, 37, 0), (6, 1, 0)])
-def test_tick_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype):
+def test_tick_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype, mode):
     tr = synth.make_trace(n, 6, m, straight_every=3)
-    a, b = pair_of_filters(hip, n, dtype)
+    a, b = pair_of_filters(hip, n, dtype, mode)
     for t in range(tr.ticks):
         ia = a.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
         ib = b.tick(tr.tw[t], tr.mx[t], tr.my[t], known_ids=tr.ids[t])
@@ -45,12 +48,13 @@ def test_tick_pipeline_equals_per_correction_kernels_cold_start(hip, n, m, dtype
         assert same(a, b), "tick %d" % t
 
 
-def test_tick_pipeline_decision_chain_edges(hip):
+@pytest.mark.parametrize("mode", [1, 3], ids=["one-launch", "two-launches"])
+def test_tick_pipeline_decision_chain_edges(hip, mode):
     """skip (id -1), break (id > total_landmarks: the rest of the tick is dropped), out-of-range id (latched
     NUSLAM_E_BOUNDS), the same landmark twice in one tick, a first sighting followed by a re-sighting in one tick."""
     n, m = 12, 8
     tr = synth.make_trace(n, 5, m)
-    a, b = pair_of_filters(hip, n)
+    a, b = pair_of_filters(hip, n, 0, mode)
     cases = []
     ids = tr.ids[0].copy(); ids[2] = -1; ids[5] = ids[1]; cases.append((ids, n))            # skip + duplicate (second one: re-sighting)
     ids = tr.ids[1].copy(); ids[3] = -1; ids[4] = ids[0]; cases.append((ids, n))
@@ -101,7 +105,7 @@ def test_tick_pipeline_n1000_matches_oracle_and_pairs(hip):
     o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O.ORC_STRUCTURED)
     o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=wid)
     fs = []
-    for mode, pairing in ((1, True), (0, True), (0, False)):
+    for mode, pairing in ((1, True), (3, True), (0, True), (0, False)):
         g = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
         g.restore(o.state.copy(), o.cov.copy(), o.seen)
         bt = g.as_batch()
