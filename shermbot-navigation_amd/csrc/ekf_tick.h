@@ -95,6 +95,11 @@ __device__ inline void st_agent(double* p, double x) { __hip_atomic_store(p, x, 
 #endif
 __device__ inline void st_agent(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_agent(int* p, int x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_agent(float* p, float x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline float ld_agent(const float* p)
+{
+    return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ inline double ld_agent(const double* p)
 {
     return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -178,6 +183,73 @@ __global__ __launch_bounds__(64) void k_tick_wait(const int* __restrict__ cnt, i
 __global__ __launch_bounds__(64) void k_tick_signal(int* __restrict__ cnt)
 {
     if (threadIdx.x == 0) tick_signal(cnt);
+}
+
+// predict() on a 35 x 35 block of P at the index set U and on the state there, exactly as k_predict writes them into the
+// full covariance (slam_library.cpp:65-148: pose advance, A = I + B at the advanced heading, A P A^T + Qbar restricted to the
+// block; positions 0, 1, 2 of U are the pose).  FBs / SF: block and state before, BKo / SMo: after.  256 threads.
+template <typename T>
+__device__ inline void predict_block(const View& v, const TwistArg& tw, int b, const double (*FBs)[kTickNU + 1],
+                                     double (*BKo)[kTickNU + 1], const double* SF, double* SMo)
+{
+    constexpr int NU = kTickNU, NT = 256;
+    const int tid = threadIdx.x;
+    const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
+    const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
+    const double theta = SF[0];
+    double dq_th, dq_x, dq_y;
+    if (dth == 0.0) {
+        dq_th = 0.0;
+        dq_x = dx * cos(theta);
+        dq_y = dx * sin(theta);
+    } else {
+        dq_th = dth;
+        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
+        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
+    }
+    const double th1 = theta + dq_th;
+    double a1, a2;
+    if (dth == 0) {
+        a1 = -dx * sin(th1);
+        a2 = dx * cos(th1);
+    } else {
+        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
+        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
+    }
+    if (tid < NU) {
+        const int p = tid;
+        SMo[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
+    }
+    if (tid == 0) {
+        double pp[3][3], tt[3][3], u[3][3];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) pp[i][j] = FBs[i][j];
+        for (int j = 0; j < 3; ++j) {
+            tt[0][j] = pp[0][j];
+            tt[1][j] = a1 * pp[0][j] + pp[1][j];
+            tt[2][j] = a2 * pp[0][j] + pp[2][j];
+        }
+        for (int i = 0; i < 3; ++i) {
+            u[i][0] = tt[i][0];
+            u[i][1] = tt[i][0] * a1 + tt[i][1];
+            u[i][2] = tt[i][0] * a2 + tt[i][2];
+        }
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) BKo[i][j] = (double)(T)(u[i][j] + v.Q[i + 3 * j]);
+    }
+    for (int e = tid; e < NU * NU; e += NT) {
+        const int p = e / NU, q = e % NU;
+        if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
+        double val = FBs[p][q];
+        if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
+            const double p0 = FBs[0][q];
+            val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
+        } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
+            const double t0 = FBs[p][0];
+            val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
+        }
+        BKo[p][q] = val;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the next tick's start
@@ -301,62 +373,7 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
     __syncthreads();
 
     // ---- this tick's predict on the block and the pose, as k_predict does it (slam_library.cpp:65-148)
-    const double dth = cy.tw.tw ? cy.tw.tw[b * cy.tw.stride + cy.tw.off + 0] : cy.tw.dth0;
-    const double dx = cy.tw.tw ? cy.tw.tw[b * cy.tw.stride + cy.tw.off + 1] : cy.tw.dx0;
-    const double theta = SF[0];
-    double dq_th, dq_x, dq_y;
-    if (dth == 0.0) {
-        dq_th = 0.0;
-        dq_x = dx * cos(theta);
-        dq_y = dx * sin(theta);
-    } else {
-        dq_th = dth;
-        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
-        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
-    }
-    const double th1 = theta + dq_th;
-    double a1, a2;
-    if (dth == 0) {
-        a1 = -dx * sin(th1);
-        a2 = dx * cos(th1);
-    } else {
-        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
-        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
-    }
-    if (tid < NU) {
-        const int p = tid;
-        SMo[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
-    }
-    if (tid == 0) {
-        double pp[3][3], tt[3][3], u[3][3];
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) pp[i][j] = FBs[i][j];
-        for (int j = 0; j < 3; ++j) {
-            tt[0][j] = pp[0][j];
-            tt[1][j] = a1 * pp[0][j] + pp[1][j];
-            tt[2][j] = a2 * pp[0][j] + pp[2][j];
-        }
-        for (int i = 0; i < 3; ++i) {
-            u[i][0] = tt[i][0];
-            u[i][1] = tt[i][0] * a1 + tt[i][1];
-            u[i][2] = tt[i][0] * a2 + tt[i][2];
-        }
-        for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) BKo[i][j] = (double)(T)(u[i][j] + v.Q[i + 3 * j]);
-    }
-    for (int e = tid; e < NU * NU; e += NT) {
-        const int p = e / NU, q = e % NU;
-        if (p < 3 && q < 3) continue;                                   // the corner: thread 0 above
-        double val = FBs[p][q];
-        if (q >= 3 && (p == 1 || p == 2)) {                             // column role: rows 1, 2 of a landmark column
-            const double p0 = FBs[0][q];
-            val = (double)(T)((p == 1 ? a1 : a2) * p0 + val);
-        } else if (p >= 3 && (q == 1 || q == 2)) {                      // row role: columns 1, 2 of a landmark row
-            const double t0 = FBs[p][0];
-            val = (double)(T)(t0 * (q == 1 ? a1 : a2) + val);
-        }
-        BKo[p][q] = val;
-    }
+    predict_block<T>(v, cy.tw, b, FBs, BKo, SF, SMo);
     const int* c4 = ctrl4 + 4 * b;
     seen = c4[0]; cached = c4[0]; brk = 0; status = c4[3];              // slam.cpp:250-251 at this tick's top
     __syncthreads();
@@ -373,9 +390,13 @@ __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz
 // runs on: every plan entry is stored with agent-scope stores and announced through *pub_flag = pub_base + (entries
 // complete) -- one correction late, at a point where the storing waves' vmcnt(0) waits are free (their stores are >1 us old).
 struct TickPublish {
-    int* flag;             // per filter: pub_base + number of complete plan entries of this round
-    int base;
+    int* flag;             // per filter, kPubWords ints: [0] pub_base + number of complete plan entries of this round;
+    int base;              // (predict fused in, below) [1] the chain has gathered its block, [2] predict workgroups done
+    int predict;           // != 0: this launch also holds the tick's predict (k_tick_front's middle workgroups)
+    int gbase, pbase;      // the values [1] / [2] reach when that has happened
+    TwistArg tw;
 };
+constexpr int kPubWords = 4;
 __device__ inline void plan_store(bool publish, double* p, double x)
 {
     if (publish) st_agent(p, x);
@@ -436,6 +457,18 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         if (tid < NU) SM[0][tid] = s[Ush[tid]];
         const int* ci = v.c_in + b * C_WORDS;
         seen = ci[C_SEEN]; brk = ci[C_BRK]; status = ci[C_STATUS]; cached = ci[C_SEEN_CACHED];
+        if (PUBLISH && pub.predict) {
+            // The tick's predict runs in THIS launch (the middle workgroups of k_tick_front rewrite rows / columns 1, 2 of P in
+            // place): what was just gathered is the covariance BEFORE it.  Let them go, and apply predict to the block and
+            // the pose here, with k_predict's own arithmetic (predict_block); the tick's bookkeeping (slam.cpp:250-251) too.
+            __syncthreads();                                            // (every gathered value has arrived)
+            if (tid == 0) st_agent(pub.flag + kPubWords * b + 1, pub.gbase);
+            for (int e = tid; e < NU * (NU + 1); e += 256) (&BK[1][0][0])[e] = (&BK[0][0][0])[e];
+            if (tid < NU) SM[1][tid] = SM[0][tid];
+            __syncthreads();
+            predict_block<T>(v, pub.tw, b, BK[1], BK[0], SM[1], SM[0]);
+            cached = seen; brk = 0;
+        }
     }
     if (wave == 3 && lane < kTickJ) {             // all markers' polar forms at once, one lane each
         double a = 0.0, bb = 0.0;
@@ -671,7 +704,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         } else if (PUBLISH && tid == 192) {
             // entries 0 .. st-1 are complete: wave 0 waited for its stores at the end of phase 1, wave 2 at the top of phase
             // 2, both in front of the barrier just passed
-            st_agent(pub.flag + b, pub.base + st);
+            st_agent(pub.flag + kPubWords * b, pub.base + st);
         }
         CK(4);
         lds_barrier();
@@ -694,7 +727,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     if (PUBLISH) {                                                      // the whole round is complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) st_agent(pub.flag + b, pub.base + J);
+        if (tid == 0) st_agent(pub.flag + kPubWords * b, pub.base + J);
     }
     if (tid == 0) {
         int* co = v.c_out + b * C_WORDS;
@@ -712,7 +745,7 @@ __global__ __launch_bounds__(256) void k_tick_chain(View v, TickObs o, int total
                                                     TickStep* __restrict__ plan, TickCarry cy,
                                                     int* __restrict__ ctrl_out4, int* __restrict__ done_cnt)
 {
-    tick_chain<T, FUSED, false>(blockIdx.x, v, o, total_landmarks, P, plan, cy, ctrl_out4, done_cnt, TickPublish{ nullptr, 0 });
+    tick_chain<T, FUSED, false>(blockIdx.x, v, o, total_landmarks, P, plan, cy, ctrl_out4, done_cnt, TickPublish{});
 }
 
 // ------------------------------------------------------------------------------------------------ overlapped runs: prep
@@ -1036,12 +1069,36 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     const bool owner = live && k == 0;
     double* const dump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
     double PN[kQuadRows];
-#pragma unroll
-    for (int j = 0; j < kQuadRows; ++j)
-        PN[j] = role == 0 ? (double)Pb[(size_t)tr * ld + Uk[j]] : (double)Pb[(size_t)Uk[j] * ld + tr];
-    double sv = role == 1 ? v.s_in[(size_t)b * ld + tr] : 0.0;
-    const long long* src = reinterpret_cast<const long long*>(plan + (size_t)b * kTickJ);
+    double sv = 0.0;
     bool failed = false;
+    if (pub.predict) {
+        // the tick's predict is being applied by workgroups of this launch: wait for all of them, then read what they wrote
+        // (rows / columns 1, 2 of P, the advanced state in s_out) with agent-scope loads -- every load of handed-off bytes
+        if (threadIdx.x == 0) {
+            int ok = 0;
+            for (int it = 0; it < (1 << 18); ++it) {
+                if (ld_agent(pub.flag + kPubWords * b + 2) - pub.pbase >= 0) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            ok_sh = ok;
+        }
+        __syncthreads();
+        if (!ok_sh) {
+            failed = true;
+            if (threadIdx.x == 0) atomicAdd(timeouts, 1);
+        }
+        __syncthreads();                                                // (ok_sh is rewritten by the entry loop)
+#pragma unroll
+        for (int j = 0; j < kQuadRows; ++j)
+            PN[j] = role == 0 ? (double)ld_agent(&Pb[(size_t)tr * ld + Uk[j]]) : (double)ld_agent(&Pb[(size_t)Uk[j] * ld + tr]);
+        if (role == 1) sv = ld_agent(&v.s_out[(size_t)b * ld + tr]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kQuadRows; ++j)
+            PN[j] = role == 0 ? (double)Pb[(size_t)tr * ld + Uk[j]] : (double)Pb[(size_t)Uk[j] * ld + tr];
+        if (role == 1) sv = v.s_in[(size_t)b * ld + tr];
+    }
+    const long long* src = reinterpret_cast<const long long*>(plan + (size_t)b * kTickJ);
 
 #pragma unroll
     for (int st = 0; st < kTickJ; ++st) {
@@ -1050,7 +1107,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
             if (threadIdx.x == 0) {
                 int ok = 0;
                 for (int it = 0; it < (1 << 18); ++it) {
-                    if (ld_agent(pub.flag + b) - (pub.base + st + 1) >= 0) { ok = 1; break; }
+                    if (ld_agent(pub.flag + kPubWords * b) - (pub.base + st + 1) >= 0) { ok = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 ok_sh = ok;
@@ -1137,16 +1194,96 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
 }
 
+// The tick's predict as workgroups of k_tick_front (thread t: column t of rows 1, 2, row t of columns 1, 2, state entry t; thread
+// 0 the 3 x 3 corner + Q -- k_predict's arithmetic, slam_library.cpp:65-148).  They start when the chain has gathered its block
+// from the covariance BEFORE predict, store with agent-scope stores, and count themselves done for the strip workgroups.
 template <typename T>
-__global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+__device__ inline void tick_predict_role(const int b, const int blk, View v, TickPublish pub, T* __restrict__ P,
+                                         int* __restrict__ timeouts)
+{
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (int it = 0; it < (1 << 18); ++it) {
+            if (ld_agent(pub.flag + kPubWords * b + 1) - pub.gbase >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) atomicAdd(timeouts, 1);               // (goes on all the same: every wait of this launch is bounded)
+    }
+    __syncthreads();
+    const int t = blk * 256 + threadIdx.x;
+    const int ld = v.ld;
+    const double* s = v.s_in + (size_t)b * ld;
+    double* so = v.s_out + (size_t)b * ld;
+    const TwistArg& tw = pub.tw;
+    const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
+    const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
+    const double theta = s[0];
+    double dq_th, dq_x, dq_y;
+    if (dth == 0.0) {
+        dq_th = 0.0;
+        dq_x = dx * cos(theta);
+        dq_y = dx * sin(theta);
+    } else {
+        dq_th = dth;
+        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
+        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
+    }
+    const double th1 = theta + dq_th;
+    double a1, a2;
+    if (dth == 0) {
+        a1 = -dx * sin(th1);
+        a2 = dx * cos(th1);
+    } else {
+        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
+        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
+    }
+    if (t < ld) st_agent(&so[t], t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t]);
+    T* Pb = P + (size_t)b * v.p_stride;
+    if (t == 0) {
+        double p[3][3], tt[3][3], u[3][3];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) p[i][j] = (double)Pb[(size_t)j * ld + i];
+        for (int j = 0; j < 3; ++j) {
+            tt[0][j] = p[0][j];
+            tt[1][j] = a1 * p[0][j] + p[1][j];
+            tt[2][j] = a2 * p[0][j] + p[2][j];
+        }
+        for (int i = 0; i < 3; ++i) {
+            u[i][0] = tt[i][0];
+            u[i][1] = tt[i][0] * a1 + tt[i][1];
+            u[i][2] = tt[i][0] * a2 + tt[i][2];
+        }
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) st_agent(&Pb[(size_t)j * ld + i], (T)(u[i][j] + v.Q[i + 3 * j]));
+    } else if (t >= 3 && t < v.L) {
+        T* col = Pb + (size_t)t * ld;
+        const double p0 = (double)col[0];
+        const double p1 = (double)col[1];
+        const double p2 = (double)col[2];
+        const double t0 = (double)Pb[t];
+        const double r1 = (double)Pb[(size_t)1 * ld + t], r2 = (double)Pb[(size_t)2 * ld + t];
+        st_agent(&col[1], (T)(a1 * p0 + p1));
+        st_agent(&col[2], (T)(a2 * p0 + p2));
+        st_agent(&Pb[(size_t)1 * ld + t], (T)(t0 * a1 + r1));
+        st_agent(&Pb[(size_t)2 * ld + t], (T)(t0 * a2 + r2));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(pub.flag + kPubWords * b + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// grid.x = 1 (the chain) + n_pred (predict workgroups, when the tick's predict rides along) + the strip workgroups; grid.y = filter
+template <typename T>
+__global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total_landmarks, T* __restrict__ P,
                                                     TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                     double* __restrict__ Rbuf, double* __restrict__ Vbuf,
-                                                    int* __restrict__ pub_flag, int pub_base, int* __restrict__ timeouts)
+                                                    TickPublish pub, int n_pred, int* __restrict__ timeouts)
 {
-    const TickPublish pub = { pub_flag, pub_base };
     const int b = blockIdx.y;
-    if (blockIdx.x == 0) tick_chain<T, false, true>(b, v, o, total_landmarks, P, plan, TickCarry{}, nullptr, nullptr, pub);
-    else tick_panels_stream<T>(b, (int)blockIdx.x - 1, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
+    const int x = blockIdx.x;
+    if (x == 0) tick_chain<T, false, true>(b, v, o, total_landmarks, P, plan, TickCarry{}, nullptr, nullptr, pub);
+    else if (x <= n_pred) tick_predict_role<T>(b, x - 1, v, pub, P, timeouts);
+    else tick_panels_stream<T>(b, x - 1 - n_pred, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
 }
 
 // ------------------------------------------------------------------------------------------------ the pass over P

@@ -90,7 +90,7 @@ struct nuslam_batch {
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
-    int seq_pub = 0;
+    int seq_pub = 0, seq_gather = 0, seq_pred = 0;
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
     double* tk_V = nullptr;    // V_s = H_s R_s strips [B][kTickJ][2][ld]: the second factor of the rank-2m pass (ekf_rank.h)
     // the pass over P of a tick pipeline (nuslam_batch_set_pass_variant): 0 = rank-2m on the matrix cores, the exact chain
@@ -448,13 +448,13 @@ int ensure_tick_buffers(nuslam_batch* h)
     HIPCHK(hipMemsetAsync(h->tk_K, 0, sizeof(double) * ((size_t)h->B * kTickJ * 2 * h->ld + kTickDump), h->stream));
     HIPCHK(hipMemsetAsync(h->tk_V, 0, sizeof(double) * (size_t)h->B * kTickJ * 2 * h->ld, h->stream));
     { int rc = set_rank_attributes(); if (rc) return rc; }
-    HIPCHK(hipMalloc(&h->tk_pub, sizeof(int) * (size_t)h->B));
-    HIPCHK(hipMemsetAsync(h->tk_pub, 0, sizeof(int) * (size_t)h->B, h->stream));
+    HIPCHK(hipMalloc(&h->tk_pub, sizeof(int) * kPubWords * (size_t)h->B));
+    HIPCHK(hipMemsetAsync(h->tk_pub, 0, sizeof(int) * kPubWords * (size_t)h->B, h->stream));
     if (!h->tk_sync) {                             // {chain, next} completion counters, expired waits, probe words
         HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 8));
         HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
     }
-    h->seq_pub = 0;
+    h->seq_pub = h->seq_gather = h->seq_pred = 0;
     return NUSLAM_OK;
 }
 
@@ -687,8 +687,16 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
 
 // The markers of a known-id tick in rounds of up to kTickJ: k_tick_chain (serial part, one workgroup per filter),
 // k_tick_panels (the O(len) strips, one quad per state index), k_tick_apply (the one pass over P).
+// Can this handle's known-id tick take chain + strips (+ the tick's predict) as ONE launch?  Its whole grid must be resident.
+bool front_fits(const nuslam_batch* h, bool with_predict)
+{
+    const long long per_filter = 1 + (h->ld + 31) / 32 + (with_predict ? (h->ld + 255) / 256 : 0);
+    return h->front && per_filter * h->B <= h->n_cu;
+}
+
+// fused_predict != null: no predict kernel ran for this tick -- its predict rides in the first round's k_tick_front launch
 int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
-                   const double* host_my, const int* pf_ids, long long pf_stride)
+                   const double* host_my, const int* pf_ids, long long pf_stride, const TwistArg* fused_predict = nullptr)
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
     const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);   // (`seen` is cached per TICK, not per round)
@@ -697,13 +705,22 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         View v = h->view();
         int rc = NUSLAM_OK;
         const int strip_wgs = (h->ld + 31) / 32;
-        if (h->front && (long long)(1 + strip_wgs) * h->B <= h->n_cu) {
-            // chain and strips in ONE launch: the strip workgroups follow the chain entry by entry (k_tick_front)
+        const bool with_predict = fused_predict != nullptr && i0 == 0;
+        if (front_fits(h, with_predict)) {
+            // chain and strips in ONE launch: the strip workgroups follow the chain entry by entry (k_tick_front); in the
+            // tick's first round the predict rides along as workgroups of its own
             double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
-            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + strip_wgs, h->B), dim3(256), v, o, total,
-                                       (const T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, h->tk_pub, h->seq_pub, h->tk_sync + 2)));
+            const int n_pred = with_predict ? (h->ld + 255) / 256 : 0;
+            TickPublish pub;
+            pub.flag = h->tk_pub; pub.base = h->seq_pub; pub.predict = with_predict ? 1 : 0;
+            pub.gbase = h->seq_gather + 1; pub.pbase = h->seq_pred + n_pred;
+            if (with_predict) pub.tw = *fused_predict;
+            else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
+                                       (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
             if (rc) return rc;
             h->seq_pub += 2 * kTickJ;
+            if (with_predict) { h->seq_gather += 1; h->seq_pred += n_pred; }
             rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init);
             if (rc) return rc;
         } else {
@@ -725,7 +742,19 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
             const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr,
             const int* pf_ids = nullptr, long long pf_stride = 0)
 {
-    int rc = do_predict(h, tw);
+    // One filter, known ids, the tick pipeline: no predict kernel -- the predict rides in the first round's launch (k_tick_front)
+    const bool fuse_predict = known && m > 0 && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->predict_bookkeeping &&
+                              front_fits(h, true);
+    int rc = NUSLAM_OK;
+    if (fuse_predict) {
+        if (h->poisoned) return NUSLAM_E_SYNC;
+        h->last_tick = -1;
+        rc = do_tick_rounds(h, base, m, total, host_ids, host_mx, host_my, pf_ids, pf_stride, &tw);
+        if (rc) return rc;
+        h->host_seen_valid = false;
+        return NUSLAM_OK;
+    }
+    rc = do_predict(h, tw);
     if (rc) return rc;
     // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark, in every
     // filter: then the caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does
