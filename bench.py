@@ -84,6 +84,8 @@ def parse():
                     help="ekf5000: propagate with a fixed dense random Jacobian instead of the reference's A = I + B formed on the "
                          "device every tick -- a GEMM micro-measurement on fully dense operands (MFMA loops on mostly-zero "
                          "operands hold a higher clock), not the reference's predict")
+    ap.add_argument("--interleave", type=int, default=None, help="nuslam_batch_set_interleave: groups of filters on streams of their own "
+                                                                 "(batch workload; default: the library's choice, 2 for large batches)")
     ap.add_argument("--parity-ticks", type=int, default=40, help="ticks of the same-run parity leg (through nuslam_batch_run)")
     ap.add_argument("--no-api", action="store_true", help="skip the api_driven leg (the C++ class driven call by call)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
@@ -427,6 +429,8 @@ def main():
         bt.set_pass_variant(1)
     if args.pass_variant is not None:
         bt.set_pass_variant(args.pass_variant)
+    if args.interleave is not None:
+        bt.set_interleave(args.interleave)
     if args.no_overlap:
         bt.set_overlap(False)
     if args.overlap:

@@ -202,6 +202,12 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
  * rank-2m pass (one stream is the faster order there), on for one filter / off for batches with the exact chain.
  * Should a hand-off expire all the same (NUSLAM_E_SYNC), the handle refuses further ticks until it is restored. */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
+/* nuslam_batch_run on a known-id trace, large batches: the filters are dealt into `groups` contiguous groups (1..4), each
+ * running its ticks on a stream of its own, so that one group's HBM-bound pass over the covariance overlaps another group's
+ * latency- and VALU-bound chain and strips (independent filters: nothing is exchanged).  Same kernels on the same
+ * per-filter data: same bits for every group count.  Default 1 (off): measured at 1024 x N = 200 the groups' kernels only take
+ * turns at the same resources (16.0 -> 16.3 M updates/s); kept as a measurement switch. */
+int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups);
 /* How a tick pipeline's ONE pass over the covariance applies the round's corrections.
  *   0 (default)  as a rank-2m update on the matrix cores: update()'s P <- (I - K H) P (slam_library.cpp:279) re-associated
  *                as P - K (H P), all corrections of the round in one v_mfma_f64 accumulation per tile -- 2 FMAs per element

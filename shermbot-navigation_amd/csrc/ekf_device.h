@@ -27,6 +27,9 @@ struct View {
     int aslot;            //        used alternately: the consumer of slot s re-arms slot s^1)
     int* id_log;          // [B][log_stride] resolved id per observation of the current tick (may be null)
     int log_stride;
+    double* dump;         // kTickDump doubles nobody reads: where lanes of the strip kernels that own nothing store (null until the
+                          // tick pipeline's buffers exist).  A pointer of its own, not "behind filter B's strips": a launch may
+                          // cover a sub-range of the handle's filters
     double Q[9];          // 3x3 column-major process noise   (slam_library.hpp:27)
     double R[4];          // 2x2 column-major sensor noise    (slam_library.hpp:28)
 };

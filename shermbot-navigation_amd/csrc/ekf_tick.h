@@ -874,7 +874,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         // (An `if` around the stores ends the basic block: with sixteen unrolled corrections the scheduler could then not
         // move a correction's LDS reads of the plan above the previous correction's arithmetic, and every correction
         // started with exposed LDS round trips -- one wave per SIMD here, nothing else to run meanwhile.)
-        double* const rdump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
+        double* const rdump = v.dump + (threadIdx.x & (kTickDump - 1));
         double* const rdst = (live && k == 0) ? Rb + t : rdump;
         const size_t rstep = (live && k == 0) ? (size_t)ld : 0;
         double* const vdst = (Vbuf && live && k == 0) ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : rdump;
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         const bool live = t < ld;
         const int tr = live ? t : 0;
         const int pm = (posmap && live && k == 0) ? posmap[(size_t)b * ld + t] : -1;
-        double* const kdump = Kbuf + (size_t)v.B * kTickJ * 2 * ld + (threadIdx.x & (kTickDump - 1));
+        double* const kdump = v.dump + (threadIdx.x & (kTickDump - 1));
         double* const kdst = (live && k == 0) ? Kb + t : kdump;
         const size_t kstep = (live && k == 0) ? (size_t)ld : 0;
         double* const kudump = KU ? KU + (size_t)v.B * kTickJ * 2 * NU + (threadIdx.x & (kTickDump - 1)) : nullptr;
@@ -1067,7 +1067,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     const bool live = role == 0 ? t < L : t < ld;
     const int tr = live ? t : 0;
     const bool owner = live && k == 0;
-    double* const dump = Rbuf + (size_t)v.B * kTickJ * 5 * ld + (threadIdx.x & (kTickDump - 1));
+    double* const dump = v.dump + (threadIdx.x & (kTickDump - 1));
     double PN[kQuadRows];
     double sv = 0.0;
     bool failed = false;

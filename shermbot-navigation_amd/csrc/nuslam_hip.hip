@@ -91,6 +91,14 @@ struct nuslam_batch {
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
     int seq_pub = 0, seq_gather = 0, seq_pred = 0;
+    // Interleaved groups (nuslam_batch_set_interleave): a batch's known-id ticks run as G independent groups of filters, each on
+    // a stream of its own, so that one group's HBM-bound pass over P overlaps another group's latency- / VALU-bound chain and
+    // strips.  Same kernels on the same per-filter data: same bits.  -1: the library picks (2 for large batches).
+    int groups = -1;
+    hipStream_t gstream[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t gev[4] = { nullptr, nullptr, nullptr, nullptr }, gev0 = nullptr;
+    hipEvent_t gpass[4] = { nullptr, nullptr, nullptr, nullptr };   // group g's last pass over P is done
+    bool gpass_set[4] = { false, false, false, false };
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
     double* tk_V = nullptr;    // V_s = H_s R_s strips [B][kTickJ][2][ld]: the second factor of the rank-2m pass (ekf_rank.h)
     // the pass over P of a tick pipeline (nuslam_batch_set_pass_variant): 0 = rank-2m on the matrix cores, the exact chain
@@ -152,6 +160,7 @@ struct nuslam_batch {
         v.c_in = ctrl[cidx]; v.c_out = ctrl[cidx ^ 1];
         v.p_stride = p_stride;
         v.cur_id = cur_id; v.akey = akey; v.aslot = aslot; v.id_log = id_log; v.log_stride = log_stride;
+        v.dump = tk_R ? tk_R + (size_t)B * kTickJ * 5 * ld : nullptr;
         memcpy(v.Q, Q, sizeof(Q));
         memcpy(v.R, R, sizeof(R));
         return v;
@@ -477,18 +486,38 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
     return o;
 }
 
+// A contiguous range of the handle's filters and the stream its launches go to (interleaved groups); default: all of them
+struct Sub {
+    int g0, Bg;
+    hipStream_t st;
+};
+Sub whole(const nuslam_batch* h) { return Sub{ 0, h->B, h->stream }; }
+// the view of filters [g0, g0 + Bg): every per-filter pointer moved up, B = Bg (kernels index their filters from 0)
+View sub_view(const View& v, const Sub& sb)
+{
+    View w = v;
+    w.B = sb.Bg;
+    w.s_in += (size_t)sb.g0 * v.ld; w.s_out += (size_t)sb.g0 * v.ld;
+    w.c_in += (size_t)sb.g0 * C_WORDS; w.c_out += (size_t)sb.g0 * C_WORDS;
+    w.cur_id += sb.g0; w.akey += 2 * (size_t)sb.g0;
+    if (w.id_log) w.id_log += (size_t)sb.g0 * v.log_stride;
+    return w;
+}
+template <typename T> T* filt(void* base, const nuslam_batch* h, const Sub& sb) { return (T*)base + (size_t)sb.g0 * h->p_stride; }
+
 // ---- the rank-2m pass (ekf_rank.h): tile shapes <RB, CB, WR, WC> per storage type
 template <typename T, int RB, int CB, int WR, int WC>
-int launch_rank_t(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init)
+int launch_rank_t(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init, const Sub& sb)
 {
     typedef RankTile<T, RB, CB, WR, WC> TL;
     const int tiles_r = (h->ld + TL::WROWS - 1) / TL::WROWS, tiles_c = (h->L + TL::WCOLS - 1) / TL::WCOLS;
-    const bool by_filter = h->B >= 8;                 // a filter per XCD (its strips in one L2), else tile rows per XCD
-    const dim3 grid = by_filter ? dim3((unsigned)(((h->B + 7) / 8) * 8 * tiles_r * tiles_c))
-                                : dim3((unsigned)(((tiles_r + 7) / 8) * 8 * tiles_c), (unsigned)h->B);
-    return launch_lds(h, NUSLAM_K_TICK_RANK, k_tick_rank<T, RB, CB, WR, WC>, grid, dim3(TL::NT), TL::lds_bytes, v, J, plan,
-                      (const double*)h->tk_K, (const double*)h->tk_V, (const T*)h->P(), (T*)h->Palt(), check_init, tiles_r,
-                      tiles_c, by_filter ? 1 : 0);
+    const bool by_filter = sb.Bg >= 8;                // a filter per XCD (its strips in one L2), else tile rows per XCD
+    const dim3 grid = by_filter ? dim3((unsigned)(((sb.Bg + 7) / 8) * 8 * tiles_r * tiles_c))
+                                : dim3((unsigned)(((tiles_r + 7) / 8) * 8 * tiles_c), (unsigned)sb.Bg);
+    const size_t so = (size_t)sb.g0 * kTickJ * 2 * h->ld;
+    return launch_on(h, sb.st, NUSLAM_K_TICK_RANK, k_tick_rank<T, RB, CB, WR, WC>, grid, dim3(TL::NT), TL::lds_bytes, sub_view(v, sb), J,
+                     plan + (size_t)sb.g0 * kTickJ, (const double*)h->tk_K + so, (const double*)h->tk_V + so,
+                     (const T*)filt<T>(h->P(), h, sb), filt<T>(h->Palt(), h, sb), check_init, tiles_r, tiles_c, by_filter ? 1 : 0);
 }
 #define RANK_TILES(X)                                                                           \
     X(double, 4, 1, 1, 4) X(double, 1, 4, 4, 1) X(double, 2, 2, 2, 2) X(double, 2, 2, 1, 4)       \
@@ -502,66 +531,69 @@ int set_rank_attributes()
 #undef X
     return NUSLAM_OK;
 }
-int launch_rank(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init)
+int launch_rank(nuslam_batch* h, const View& v, int J, const TickStep* plan, int check_init, const Sub& sb)
 {
     // tile 0 is the measured best per storage type (profiles/r03/pass_tiles.txt); 1..3 stay selectable for measurement
     // (nuslam_batch_set_pass_variant(10 + k)) -- every tile computes the same bits
     if (h->dtype == NUSLAM_F64) {
         switch (h->rank_tile) {
-        case 1: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init);
-        case 2: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init);
-        case 3: return launch_rank_t<double, 2, 2, 1, 4>(h, v, J, plan, check_init);
-        default: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init);
+        case 1: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init, sb);
+        case 2: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init, sb);
+        case 3: return launch_rank_t<double, 2, 2, 1, 4>(h, v, J, plan, check_init, sb);
+        default: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init, sb);
         }
     }
     switch (h->rank_tile) {
-    case 1: return launch_rank_t<float, 2, 2, 1, 4>(h, v, J, plan, check_init);
-    case 2: return launch_rank_t<float, 1, 4, 4, 1>(h, v, J, plan, check_init);
-    case 3: return launch_rank_t<float, 1, 4, 2, 2>(h, v, J, plan, check_init);
-    default: return launch_rank_t<float, 2, 1, 1, 4>(h, v, J, plan, check_init);
+    case 1: return launch_rank_t<float, 2, 2, 1, 4>(h, v, J, plan, check_init, sb);
+    case 2: return launch_rank_t<float, 1, 4, 4, 1>(h, v, J, plan, check_init, sb);
+    case 3: return launch_rank_t<float, 1, 4, 2, 2>(h, v, J, plan, check_init, sb);
+    default: return launch_rank_t<float, 2, 1, 1, 4>(h, v, J, plan, check_init, sb);
     }
 }
 
 // The pass over P of one round from the plan and the strips in tk_K / tk_R / tk_V.  may_init: the host cannot rule out a
 // first sighting in this round (it can for known ids at or below its proven lower bound of `seen`): then the rank-2m pass
 // checks the plan's flags per filter and the exact chain is launched behind it for the filters it left.
-int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, bool shares_chip, bool may_init)
+int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, bool shares_chip, bool may_init, const Sub& sb)
 {
     int only_if_init = 0;
     if (h->pass_mode == 0) {
-        int rc = launch_rank(h, v, J, plan, may_init ? 1 : 0);
+        int rc = launch_rank(h, v, J, plan, may_init ? 1 : 0, sb);
         if (rc || !may_init) return rc;
         only_if_init = 1;
     }
     const int vec = 16 / (int)h->esize();                      // rows per lane: 16 bytes' worth
     const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    const int waves = sweep_waves(h, vec, strips);
+    const int waves = sweep_waves(h, vec, strips);             // (by the handle's size: every group takes the same kernel)
     int rc = NUSLAM_OK;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, h->B), block(64 * waves);
+    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + waves - 1) / waves, sb.Bg), block(64 * waves);
     // one resident generation (waves == 8): the gain rows staged in LDS, shared by the workgroup's waves; many
     // generations (waves == 4): gain rows from L2, R alone in LDS, three workgroups per CU (see k_tick_apply)
     const bool k_in_lds = waves == 8 || h->dtype != NUSLAM_F64;
     const size_t lds = sizeof(double) * ((k_in_lds ? (size_t)J * 2 * 64 * vec : 0) + (size_t)waves * J * 5 * kSweepCW);
+    const View w = sub_view(v, sb);
+    const TickStep* pl = plan + (size_t)sb.g0 * kTickJ;
+    const double* Kp = (const double*)h->tk_K + (size_t)sb.g0 * kTickJ * 2 * h->ld;
+    const double* Rp = (const double*)h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
     if (h->dtype == NUSLAM_F64) {
+        const double* Pi = filt<double>(h->P(), h, sb);
+        double* Po = filt<double>(h->Palt(), h, sb);
         // (an overlapped run keeps k_tick_apply: its 164 registers leave room for the chain's workgroup on the same SIMDs; beside
         // the two-unit kernel's 206 the chain had to wait for a CU of its own and the pass took 51 us instead of 40)
         if (waves == 8 && h->apply_units && !shares_chip)
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply_units<8>, grid, block,
-                            sizeof(double) * (size_t)J * (5 * 128 + 8 * 5 * 8), v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
+            rc = launch_on(h, sb.st, NUSLAM_K_TICK_APPLY, k_tick_apply_units<8>, grid, block,
+                           sizeof(double) * (size_t)J * (5 * 128 + 8 * 5 * 8), w, J, pl, Kp, Rp, Pi, Po, only_if_init);
         else if (waves == 8)
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
+            rc = launch_on(h, sb.st, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 8, 2, true>, grid, block, lds, w, J, pl, Kp, Rp, Pi, Po, only_if_init);
         else
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2, false>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const double*)h->P(), (double*)h->Palt(), only_if_init);
+            rc = launch_on(h, sb.st, NUSLAM_K_TICK_APPLY, k_tick_apply<double, 4, 2, false>, grid, block, lds, w, J, pl, Kp, Rp, Pi, Po, only_if_init);
     } else {
+        const float* Pi = filt<float>(h->P(), h, sb);
+        float* Po = filt<float>(h->Palt(), h, sb);
         if (waves == 8)
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt(), only_if_init);
+            rc = launch_on(h, sb.st, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 8, 4, true>, grid, block, lds, w, J, pl, Kp, Rp, Pi, Po, only_if_init);
         else
-            rc = launch_lds(h, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4, true>, grid, block, lds, v, J, plan, (const double*)h->tk_K,
-                            (const double*)h->tk_R, (const float*)h->P(), (float*)h->Palt(), only_if_init);
+            rc = launch_on(h, sb.st, NUSLAM_K_TICK_APPLY, k_tick_apply<float, 4, 4, true>, grid, block, lds, w, J, pl, Kp, Rp, Pi, Po, only_if_init);
     }
     return rc;
 }
@@ -613,7 +645,7 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     if (rc) return rc;
     rc = between();
     if (rc) return rc;
-    return launch_pass(h, v, o.J, plan, compact, may_init);
+    return launch_pass(h, v, o.J, plan, compact, may_init, whole(h));
 }
 
 int ensure_da_buffers(nuslam_batch* h)
@@ -676,7 +708,7 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
                         (const double*)h->tk_R, h->tk_V);
             if (rc) return rc;
         }
-        rc = launch_pass(h, v, o.J, h->tk_plan, false, true);  // (association decides on the device whether a landmark is new)
+        rc = launch_pass(h, v, o.J, h->tk_plan, false, true, whole(h));  // (association decides on the device whether a landmark is new)
         if (rc) return rc;
         h->sidx ^= 1;
         h->cidx ^= 1;
@@ -721,7 +753,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             if (rc) return rc;
             h->seq_pub += 2 * kTickJ;
             if (with_predict) { h->seq_gather += 1; h->seq_pred += n_pred; }
-            rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init);
+            rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init, whole(h));
             if (rc) return rc;
         } else {
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
@@ -734,6 +766,113 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         h->cidx ^= 1;
         h->pidx ^= 1;
     }
+    return NUSLAM_OK;
+}
+
+// ---- interleaved groups
+int group_count(const nuslam_batch* h)
+{
+    int g = h->groups < 0 ? 1 : h->groups;
+    if (g > 4) g = 4;
+    if (g > h->B) g = h->B;
+    return g < 1 ? 1 : g;
+}
+Sub group_of(nuslam_batch* h, int g, int G)
+{
+    const int g0 = (int)((long long)h->B * g / G), g1 = (int)((long long)h->B * (g + 1) / G);
+    return Sub{ g0, g1 - g0, g == 0 ? h->stream : h->gstream[g] };
+}
+int ensure_groups(nuslam_batch* h, int G)
+{
+    for (int g = 1; g < G; ++g)
+        if (!h->gstream[g]) {
+            HIPCHK(hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
+        }
+    if (!h->gev0) HIPCHK(hipEventCreateWithFlags(&h->gev0, hipEventDisableTiming));
+    for (int g = 0; g < G; ++g)
+        if (!h->gpass[g]) HIPCHK(hipEventCreateWithFlags(&h->gpass[g], hipEventDisableTiming));
+    return NUSLAM_OK;
+}
+// the group streams start behind everything the handle's stream holds / the handle's stream goes on behind all of them
+int groups_fork(nuslam_batch* h, int G)
+{
+    HIPCHK(hipEventRecord(h->gev0, h->stream));
+    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->gev0, 0));
+    for (int g = 0; g < 4; ++g) h->gpass_set[g] = false;
+    return NUSLAM_OK;
+}
+int groups_join(nuslam_batch* h, int G)
+{
+    for (int g = 1; g < G; ++g) {
+        HIPCHK(hipEventRecord(h->gev[g], h->gstream[g]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->gev[g], 0));
+    }
+    return NUSLAM_OK;
+}
+
+// One known-id tick of a large batch as G groups of filters on G streams: predict, chain, strips and the pass of each group
+// are enqueued on the group's own stream, so the groups' phases slide against each other on the chip.  Same kernels, same
+// per-filter data as the ungrouped tick: same bits.  (The caller forks / joins the streams around a run of such ticks.)
+int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& base, int m, int total, const int* host_ids,
+                    const int* pf_ids, long long pf_stride)
+{
+    if (h->poisoned) return NUSLAM_E_SYNC;
+    h->last_tick = -1;
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    int rc = NUSLAM_OK;
+    {   // ---- predict (slam_library.cpp:65-148)
+        const View v = h->view();
+        for (int g = 0; g < G && !rc; ++g) {
+            const Sub sb = group_of(h, g, G);
+            TwistArg twg = tw;
+            if (twg.tw) twg.off += (long long)sb.g0 * twg.stride;
+            dim3 grid((h->ld + 255) / 256, 1, sb.Bg), block(256);
+            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, 0, sub_view(v, sb), twg,
+                                          filt<T>(h->P(), h, sb), h->predict_bookkeeping, (T*)nullptr)));
+        }
+        if (rc) return rc;
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+    }
+    const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);
+    double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
+    for (int i0 = 0; i0 < m; i0 += kTickJ) {
+        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, nullptr, nullptr);
+        const View v = h->view();
+        for (int g = 0; g < G && !rc; ++g) {
+            const Sub sb = group_of(h, g, G);
+            const View w = sub_view(v, sb);
+            TickObs og = o;
+            og.off += (long long)sb.g0 * og.stride;                     // (a broadcast trace has stride 0)
+            TickStep* pl = h->tk_plan + (size_t)sb.g0 * kTickJ;
+            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(sb.Bg), dim3(256), 0, w, og, total,
+                                          (const T*)filt<T>(h->P(), h, sb), pl, TickCarry{}, (int*)nullptr, (int*)nullptr)));
+            if (rc) break;
+            double* Kp = h->tk_K + (size_t)sb.g0 * kTickJ * 2 * h->ld;
+            double* Rp = h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
+            double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
+            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
+                                          sizeof(TickStep) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
+                                          (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr)));
+            if (rc) break;
+            // The passes take turns: group g's pass starts when group g-1's (for group 0: the last group's of the previous
+            // round) has ended.  Left to themselves the groups run in step -- pass beside pass, strips beside strips -- and
+            // each kernel just takes G times as long; with the passes in a ring, one group's HBM-bound pass always runs beside
+            // the other groups' chains and strips.
+            const int prev = (g + G - 1) % G;
+            if (h->gpass_set[prev]) HIPCHK(hipStreamWaitEvent(sb.st, h->gpass[prev], 0));
+            rc = launch_pass(h, v, og.J, h->tk_plan, false, may_init, sb);
+            if (rc) break;
+            HIPCHK(hipEventRecord(h->gpass[g], sb.st));
+            h->gpass_set[g] = true;
+        }
+        if (rc) return rc;
+        h->sidx ^= 1;
+        h->cidx ^= 1;
+        h->pidx ^= 1;
+    }
+    h->host_seen_valid = false;
     return NUSLAM_OK;
 }
 
@@ -977,6 +1116,13 @@ void free_batch(nuslam_batch* h)
     for (auto e : h->ov_events) (void)hipEventDestroy(e);
     if (h->ov_start) (void)hipEventDestroy(h->ov_start);
     if (h->stream2 && h->stream2 != h->stream) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    for (int g = 1; g < 4; ++g) {
+        if (h->gstream[g]) { (void)hipStreamSynchronize(h->gstream[g]); (void)hipStreamDestroy(h->gstream[g]); }
+        if (h->gev[g]) (void)hipEventDestroy(h->gev[g]);
+    }
+    if (h->gev0) (void)hipEventDestroy(h->gev0);
+    for (int g = 0; g < 4; ++g)
+        if (h->gpass[g]) (void)hipEventDestroy(h->gpass[g]);
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1529,6 +1675,15 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         }
         rc = NUSLAM_OK;
     }
+    // a large batch on a known-id trace: G groups of filters on G streams (do_tick_grouped)
+    const int G = group_count(h);
+    const bool grouped = G > 1 && known_trace && h->tr_m >= 1 && tick_pipeline_pays(h, h->tr_m) && !h->deferred && !h->dense_predict &&
+                         !front_fits(h, false) && t_end > t_begin;
+    if (grouped) {
+        rc = ensure_groups(h, G);
+        if (!rc) rc = ensure_tick_buffers(h);
+        if (!rc) rc = groups_fork(h, G);
+    }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
         tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
@@ -1540,9 +1695,13 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
         const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
         const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m;
-        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
-                     (long long)h->tr_ticks * h->tr_m);
+        if (grouped)
+            rc = do_tick_grouped(h, G, tw, o, h->tr_m, total_landmarks, hid, pfid, (long long)h->tr_ticks * h->tr_m);
+        else
+            rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
+                         (long long)h->tr_ticks * h->tr_m);
     }
+    if (grouped) { int jrc = groups_join(h, G); if (!rc) rc = jrc; }
     h->id_log = saved_log;
     if (!rc && t_end > t_begin) h->last_tick = t_end - 1;
     return rc;
@@ -1673,6 +1832,13 @@ int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable)
     if (enable == 2 && h->stream2 && h->stream2 != h->stream) return NUSLAM_E_ARG;     // (the hook must be set before the first overlapped run)
     h->overlap = enable < 0 ? -1 : (enable != 0);
     if (enable == 2) h->ov_same_stream = true;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups)
+{
+    if (!h || groups > 4) return NUSLAM_E_ARG;
+    h->groups = groups < 0 ? -1 : (groups < 1 ? 1 : groups);
     return NUSLAM_OK;
 }
 
