@@ -593,7 +593,12 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 const double mx = lx - x, my = ly - y;                  // measurement(): :152-156
                 double zr_h, zb_h;
                 cartesian2polar(mx, my, zr_h, zb_h);
-                if (lane == 0) { hd[18] = zr_h; hd[19] = zb_h; }
+                // ... and the innovation, against the WRAPPED heading (:157-159, :276).  Wave 0 is wrapping it in this very
+                // phase; this wave wraps its own copy (a range reduction: same bits, and idempotent should it read the
+                // already wrapped word), so that nothing of the innovation is left for the phase behind the barrier
+                const double th_w = normalize_angle(S0[0]);
+                const double zb = normalize_angle(zb_h - th_w);
+                if (lane == 0) { hd[16] = zr[st] - zr_h; hd[17] = zphi[st] - zb; }       // :272, bearing not wrapped
             }
         }
         if (pend) {
@@ -606,9 +611,9 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             }
         }
         theta_raw = false;
-        // (PUBLISH: wave 0's stores of the previous entry -- its rows of M a correction ago, the wrapped heading at the top of
-        // this phase -- are waited for here, where this wave would wait for the head wave anyway)
-        if (PUBLISH && wave == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (PUBLISH: the stores of the previous entry -- wave 0's rows of M and wave 2's prior rows and scalars a correction ago,
+        // the wrapped heading at the top of this phase -- are waited for here: they are > 1 us old)
+        if (PUBLISH && (wave == 0 || wave == 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         CK(0);
         lds_barrier();
         CK(1);
@@ -616,46 +621,12 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         const double (*B0)[NU + 1] = BK[bcur];                          // the block before THIS correction, complete
         const int fresh = B0[pos][pos] > 1.0e9 ? 2 : 0;                 // INT_MAX (2.1e9) still on the landmark's diagonal
 
-        // ---- phase 2: the bearing against the wrapped heading (wave 1) | K, M at the rows of U (wave 0), the prior
-        // rows at the columns of U (wave 2)
+        // ---- phase 2: K, M at the rows of U and the state there (wave 0) | the prior rows at the columns of U and the plan's
+        // scalars (wave 2).  (The innovation used to be formed here by wave 1 and the state in a third phase behind one more
+        // barrier; with the wraps a range reduction it fits into phase 1, and the state follows the gain rows at once.)
         const double lx = hd[14], ly = hd[15];
         const bool sing = hi[0] != 0;
-        double KP[2] = { 0.0, 0.0 };
-        if (wave == 1) {
-            const double zb = normalize_angle(hd[19] - S0[0]);          // :157-159
-            if (lane == 0) { hd[16] = zr[st] - hd[18]; hd[17] = zphi[st] - zb; }        // :272, bearing not wrapped
-        } else if (!sing && tid < NU) {
-            const int p = tid, i = Ush[p];
-            double pc[5], Hc[10], Si[4], m[5];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];          // P(U[p], set[q])
-#pragma unroll
-            for (int q = 0; q < 10; ++q) Hc[q] = hd[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Si[q] = hd[10 + q];
-            gain_row(pc, Hc, Si, i, setv, KP, m);
-            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
-            double (*Mn)[8] = MPl[mb ^ 1];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; plan_store(PUBLISH, &ps->MP[p][q], m[q]); }
-            Mn[p][5] = bef; Mn[p][6] = aft;
-            if (!PUBLISH) {                                             // (the strip workgroups of k_tick_front form the two flags themselves)
-                ps->MP[p][5] = bef; ps->MP[p][6] = aft;
-                if (p > 0) ps->MP[p][7] = 0.0;                          // (MP[0][7]: the wrapped heading, written when it is formed)
-            }
-        } else if (wave == 2) {
-            // (PUBLISH: this wave's stores of the PREVIOUS entry -- its scalars, a phase and a head ago -- have long landed:
-            // the wait is free here, and after the barrier below entry st - 1 may be announced)
-            if (PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!sing && tid < 128 + NU) {                              // the five prior rows at the columns of U
-                const int p = tid - 128;
-#pragma unroll
-                for (int q = 0; q < 5; ++q) plan_store(PUBLISH, &ps->BR[p][q], B0[sp[q]][p]);
-            }
-        }
-        CK(2);
-        lds_barrier();
-        CK(3);
+        const double dz0 = hd[16], dz1 = hd[17];                        // z - z_hat, formed by wave 1 in phase 1
         if (sing) {                                                     // singular S: update() throws after the init
             if (status == 0) status = kStatusSingular;
             if (tid == 0) {
@@ -667,48 +638,91 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 if (i == c) SM[scur][tid] = lx;
                 if (i == c + 1) SM[scur][tid] = ly;
             }
+            CK(2);
             lds_barrier();
+            CK(3);
             continue;
         }
-        // ---- phase 3: the state at U (wave 0) and the scalars of the plan
-        const double dz0 = hd[16], dz1 = hd[17];
         if (tid < NU) {
             const int p = tid, i = Ush[p];
+            double pc[5], Hc[10], Si[4], m[5], KP[2];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];          // P(U[p], set[q])
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = hd[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si[q] = hd[10 + q];
+            gain_row(pc, Hc, Si, i, setv, KP, m);
+            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
+            double (*Mn)[8] = MPl[mb ^ 1];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; if (!PUBLISH) ps->MP[p][q] = m[q]; }
+            Mn[p][5] = bef; Mn[p][6] = aft;
+            if (!PUBLISH) {                                             // (the strip workgroups of k_tick_front form the two flags themselves)
+                ps->MP[p][5] = bef; ps->MP[p][6] = aft;
+                if (p > 0) ps->MP[p][7] = 0.0;                          // (MP[0][7]: the wrapped heading, written when it is formed)
+            }
+            // the state at U
             double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : S0[p];
             double acc = 0.0;
             acc = fma(KP[0], dz0, acc);
             acc = fma(KP[1], dz1, acc);
             sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
             SM[scur ^ 1][p] = sv;
-        } else if (PUBLISH && wave == 2) {
-            // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4], dz[2],
-            // lxy[2], contiguous behind them (a single lane storing twenty agent-scope words one after the other cost 0.4 us)
-            const int w = lane;
-            if (w < 20) {
-                long long word;
-                if (w == 0) word = (long long)(unsigned)0 | ((long long)((d.init ? 1 : 0) | fresh) << 32);
-                else if (w == 1) word = (long long)(unsigned)c | ((long long)d.id << 32);
-                else {
-                    const int f = w - 2;                                // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz = hd[16], hd[17]; 16, 17: lxy = hd[14], hd[15]
-                    word = __double_as_longlong(hd[f < 14 ? f : (f < 16 ? f + 2 : f - 2)]);
-                }
-                st_agent(reinterpret_cast<long long*>(ps) + w, word);
+        }
+        if (PUBLISH && wave == 0) {
+            // the rows of M to the plan, COALESCED: lane l of store k writes word 64 k + l of MP (rows of 8 words), read back
+            // from the LDS copy this wave has just written (a wave's LDS accesses execute in order).  With one row per lane
+            // every store instruction touched 35 different cache lines through the CU's one address path: 0.25 us of the phase.
+            const double (*Mr)[8] = MPl[mb ^ 1];
+#pragma unroll
+            for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
+                const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
+                if (p < NU && q < 5) st_agent(&ps->MP[0][0] + idx, Mr[p][q]);
             }
-        } else if (!PUBLISH && tid == 128) {
-            plan_store_head(false, ps, 0, (d.init ? 1 : 0) | fresh, c, d.id);
+        } else if (wave == 2) {
+            if (PUBLISH) {                                              // the five prior rows at the columns of U, coalesced likewise
 #pragma unroll
-            for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
+                for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
+                    const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
+                    if (p < NU && q < 5) st_agent(&ps->BR[0][0] + idx, B0[sp[q]][p]);
+                }
+            } else if (tid < 128 + NU) {
+                const int p = tid - 128;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
-            ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
+                for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
+            }
+            if (PUBLISH) {
+                // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4],
+                // dz[2], lxy[2], contiguous behind them (a single lane storing twenty agent-scope words one after the other
+                // cost 0.4 us)
+                const int w = lane;
+                if (w < 20) {
+                    long long word;
+                    if (w == 0) word = (long long)(unsigned)0 | ((long long)((d.init ? 1 : 0) | fresh) << 32);
+                    else if (w == 1) word = (long long)(unsigned)c | ((long long)d.id << 32);
+                    else {
+                        const int f = w - 2;                            // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz; 16, 17: lxy = hd[14], hd[15]
+                        word = __double_as_longlong(f < 14 ? hd[f] : (f == 14 ? dz0 : (f == 15 ? dz1 : hd[f - 2])));
+                    }
+                    st_agent(reinterpret_cast<long long*>(ps) + w, word);
+                }
+            } else if (tid == 128) {
+                plan_store_head(false, ps, 0, (d.init ? 1 : 0) | fresh, c, d.id);
+#pragma unroll
+                for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
+                ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
+            }
         } else if (PUBLISH && tid == 192) {
-            // entries 0 .. st-1 are complete: wave 0 waited for its stores at the end of phase 1, wave 2 at the top of phase
-            // 2, both in front of the barrier just passed
+            // entries 0 .. st-1 are complete: waves 0 and 2 waited for their stores at the end of phase 1, in front of the
+            // barrier just passed
             st_agent(pub.flag + kPubWords * b, pub.base + st);
         }
-        CK(4);
+        CK(2);
         lds_barrier();
-        CK(5);
+        CK(3);
         scur ^= 1;
         mb ^= 1;
         pend = true;
@@ -833,7 +847,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
     const T* Pb = P + (size_t)b * v.p_stride;
     const int J = o.J;
     double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
-    double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
+    double* Rb = Rbuf ? Rbuf + (size_t)b * kTickJ * 5 * ld : nullptr;       // (null: nobody reads the R strips of this round)
 
 #ifdef NUSLAM_CHAIN_CLOCK
     long long pct = (long long)wall_clock64();
@@ -875,8 +889,8 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         // move a correction's LDS reads of the plan above the previous correction's arithmetic, and every correction
         // started with exposed LDS round trips -- one wave per SIMD here, nothing else to run meanwhile.)
         double* const rdump = v.dump + (threadIdx.x & (kTickDump - 1));
-        double* const rdst = (live && k == 0) ? Rb + t : rdump;
-        const size_t rstep = (live && k == 0) ? (size_t)ld : 0;
+        double* const rdst = (Rb && live && k == 0) ? Rb + t : rdump;
+        const size_t rstep = (Rb && live && k == 0) ? (size_t)ld : 0;
         double* const vdst = (Vbuf && live && k == 0) ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : rdump;
         const size_t vstep = (Vbuf && live && k == 0) ? (size_t)ld : 0;
         double* const rudump = RU ? RU + (size_t)v.B * kTickJ * 5 * NU + (threadIdx.x & (kTickDump - 1)) : nullptr;

@@ -634,13 +634,16 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
 {
     int rc = NUSLAM_OK;
     double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;       // the rank-2m pass's second factor, formed beside R
+    // the five prior rows R_s themselves are read by the exact chain and by the next tick's carry only: when the host can prove
+    // that the rank-2m pass takes every filter of this round, they are not stored at all (30 of 394 us at 1024 x N = 200)
+    double* rbuf = (h->pass_mode == 0 && !may_init && !compact) ? nullptr : h->tk_R;
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
                                        h->tk_KU, h->tk_RU, h->tk_SU)));
     else
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, h->B), dim3(512),
-                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, h->tk_R, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
+                                       sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
                                        h->tk_KU, h->tk_RU, h->tk_SU)));
     if (rc) return rc;
     rc = between();
@@ -850,7 +853,7 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
                                           (const T*)filt<T>(h->P(), h, sb), pl, TickCarry{}, (int*)nullptr, (int*)nullptr)));
             if (rc) break;
             double* Kp = h->tk_K + (size_t)sb.g0 * kTickJ * 2 * h->ld;
-            double* Rp = h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
+            double* Rp = (h->pass_mode == 0 && !may_init) ? nullptr : h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
             double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
             DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
                                           sizeof(TickStep) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
