@@ -149,8 +149,9 @@ __global__ __launch_bounds__(256) void k_da_begin(View v, TickObs o, const T* __
 template <typename T>
 __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int last, int total_landmarks,
                                                  const T* __restrict__ P, DaBuf d, TickStep* __restrict__ plan,
-                                                 double* __restrict__ Kbuf, double* __restrict__ Rbuf)
+                                                 double* __restrict__ Kbuf, double* __restrict__ Rbuf, double* __restrict__ Vbuf)
 {
+    // Vbuf (may be null): V_s = H_s R_s beside R_s, the second factor of the rank-2m pass (ekf_rank.h) -- hp_entry's sum
     const int b = blockIdx.y, wg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,6 +363,11 @@ __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int 
             if (own && t < L) {
 #pragma unroll
                 for (int q = 0; q < 5; ++q) Rb[(size_t)(st * 5 + q) * ld + t] = rs[q];
+                if (Vbuf) {
+                    double* Vb = Vbuf + (size_t)b * kTickJ * 2 * ld;
+                    Vb[(size_t)(st * 2 + 0) * ld + t] = hp_entry(Hc, rs, 0);
+                    Vb[(size_t)(st * 2 + 1) * ld + t] = hp_entry(Hc, rs, 1);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 5; ++q) rcolL[lane][q] = rs[q];
@@ -536,7 +542,7 @@ __device__ long long g_da_clock[4][16];       // debug builds (make daclock): pe
 template <typename T>
 __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_landmarks, const T* __restrict__ P, DaBuf d,
                                                   TickStep* __restrict__ plan, double* __restrict__ Kbuf,
-                                                  double* __restrict__ Rbuf, int round_tag)
+                                                  double* __restrict__ Rbuf, double* __restrict__ Vbuf, int round_tag)
 {
     const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -950,6 +956,12 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 if (t < L && !nocorr) {
 #pragma unroll
                     for (int q = 0; q < 5; ++q) st_agent(&Rb[(size_t)(st * 5 + q) * ld + t], rcolL[lane][q]);
+                    if (Vbuf) {                                         // V_s = H_s R_s beside R_s (read by the NEXT kernel only: plain stores)
+                        double* Vb = Vbuf + (size_t)b * kTickJ * 2 * ld;
+                        const double rs[5] = { rcolL[lane][0], rcolL[lane][1], rcolL[lane][2], rcolL[lane][3], rcolL[lane][4] };
+                        Vb[(size_t)(st * 2 + 0) * ld + t] = hp_entry(hist[st], rs, 0);
+                        Vb[(size_t)(st * 2 + 1) * ld + t] = hp_entry(hist[st], rs, 1);
+                    }
                 }
                 if (t < ld) {
                     if (!nocorr) {

@@ -245,28 +245,4 @@ __global__ __launch_bounds__(64 * WR * WC) void k_tick_rank(View v, int J, const
     }
 }
 
-// V_s = H_s R_s from the R strips, for producers that emit R only (the unknown-association kernels of ekf_da.h):
-// thread t owns column t.  O(J len).
-__global__ __launch_bounds__(256) void k_tick_vstrips(View v, int J, const TickStep* __restrict__ plan,
-                                                     const double* __restrict__ Rbuf, double* __restrict__ Vbuf)
-{
-    const int b = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= v.L) return;
-    const int ld = v.ld;
-    const TickStep* pl = plan + (size_t)b * kTickJ;
-    const double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld + t;
-    double* Vb = Vbuf + (size_t)b * kTickJ * 2 * ld + t;
-    for (int st = 0; st < J; ++st) {
-        if (pl[st].skip) continue;
-        double rs[5], Hc[10];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) rs[q] = Rb[(size_t)(st * 5 + q) * ld];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) Hc[q] = pl[st].Hc[q];
-        Vb[(size_t)(st * 2 + 0) * ld] = hp_entry(Hc, rs, 0);
-        Vb[(size_t)(st * 2 + 1) * ld] = hp_entry(Hc, rs, 1);
-    }
-}
-
 } // namespace nuslam

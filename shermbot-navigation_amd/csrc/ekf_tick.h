@@ -121,7 +121,7 @@ __device__ inline void lds_barrier()
 }
 
 // (H_s P_{s-1})(r, j) from the five prior rows at column j: ascending-q FMA chain -- the ONE definition every producer
-// and consumer of V strips uses (k_tick_panels, k_tick_vstrips, tick_carry), so that they agree bit for bit
+// and consumer of V strips uses (k_tick_panels, k_tick_front, the association kernels, tick_carry), so that they agree bit for bit
 __device__ inline double hp_entry(const double* Hc, const double rs[5], int r)
 {
     double a = 0.0;

@@ -689,12 +689,13 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
         const TickObs o = make_tick_obs(h, base, i0, m, nullptr, host_mx, host_my);
         View v = h->view();
         int rc = NUSLAM_OK;
+        double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;   // V = H R beside R, for the rank-2m pass
         const dim3 grid(h->da.nwg, h->B), block(256);
         // all workgroups of the resident kernel must be on the chip together (they wait for each other): one per CU at most
         const bool resident = h->tick_mode != 2 && (long long)h->da.nwg * h->B <= h->n_cu;
         if (resident) {
             DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T>, grid, block, (size_t)kDaRoundLds, v, o, total,
-                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, (int)h->da_round_tag)));
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, vbuf, (int)h->da_round_tag)));
             if (rc) return rc;
             h->da_round_tag += kTickJ + 1;
         } else {
@@ -702,14 +703,9 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
             if (rc) return rc;
             for (int st = 0; st < o.J; ++st) {
                 DISPATCH_T(h, rc = (launch(h, NUSLAM_K_DA_STEP, k_da_step<T>, grid, block, v, o, st, st + 1 == o.J ? 1 : 0, total,
-                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R)));
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, vbuf)));
                 if (rc) return rc;
             }
-        }
-        if (h->pass_mode == 0) {                                // the association kernels emit R; V = H R for the rank-2m pass
-            rc = launch(h, -1, k_tick_vstrips, dim3((h->L + 255) / 256, h->B), dim3(256), v, o.J, (const TickStep*)h->tk_plan,
-                        (const double*)h->tk_R, h->tk_V);
-            if (rc) return rc;
         }
         rc = launch_pass(h, v, o.J, h->tk_plan, false, true, whole(h));  // (association decides on the device whether a landmark is new)
         if (rc) return rc;
