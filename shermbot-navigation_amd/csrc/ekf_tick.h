@@ -113,6 +113,10 @@ __device__ inline int ld_agent(const int* p)
     return __hip_atomic_load(const_cast<int*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Sequence words of the in-launch hand-offs count up for the life of a handle (a run of an hour wraps them): "has the word
+// reached the target" is decided on the wrapped difference, in unsigned arithmetic.
+__device__ inline bool seq_reached(int word, int target) { return (int)((unsigned)word - (unsigned)target) >= 0; }
+
 // Workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores
 // (__syncthreads() also drains vmcnt, i.e. waits ~1 us for the acknowledgement of every plan store in flight).
 __device__ inline void lds_barrier()
@@ -718,7 +722,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         } else if (PUBLISH && tid == 192) {
             // entries 0 .. st-1 are complete: waves 0 and 2 waited for their stores at the end of phase 1, in front of the
             // barrier just passed
-            st_agent(pub.flag + kPubWords * b, pub.base + st);
+            st_agent(pub.flag + kPubWords * b, (int)((unsigned)pub.base + (unsigned)st));
         }
         CK(2);
         lds_barrier();
@@ -741,7 +745,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     if (PUBLISH) {                                                      // the whole round is complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) st_agent(pub.flag + kPubWords * b, pub.base + J);
+        if (tid == 0) st_agent(pub.flag + kPubWords * b, (int)((unsigned)pub.base + (unsigned)J));
     }
     if (tid == 0) {
         int* co = v.c_out + b * C_WORDS;
@@ -1091,7 +1095,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         if (threadIdx.x == 0) {
             int ok = 0;
             for (int it = 0; it < (1 << 18); ++it) {
-                if (ld_agent(pub.flag + kPubWords * b + 2) - pub.pbase >= 0) { ok = 1; break; }
+                if (seq_reached(ld_agent(pub.flag + kPubWords * b + 2), pub.pbase)) { ok = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             ok_sh = ok;
@@ -1121,7 +1125,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
             if (threadIdx.x == 0) {
                 int ok = 0;
                 for (int it = 0; it < (1 << 18); ++it) {
-                    if (ld_agent(pub.flag + kPubWords * b) - (pub.base + st + 1) >= 0) { ok = 1; break; }
+                    if (seq_reached(ld_agent(pub.flag + kPubWords * b), (int)((unsigned)pub.base + (unsigned)(st + 1)))) { ok = 1; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 ok_sh = ok;
@@ -1218,7 +1222,7 @@ __device__ inline void tick_predict_role(const int b, const int blk, View v, Tic
     if (threadIdx.x == 0) {
         int ok = 0;
         for (int it = 0; it < (1 << 18); ++it) {
-            if (ld_agent(pub.flag + kPubWords * b + 1) - pub.gbase >= 0) { ok = 1; break; }
+            if (seq_reached(ld_agent(pub.flag + kPubWords * b + 1), pub.gbase)) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) atomicAdd(timeouts, 1);               // (goes on all the same: every wait of this launch is bounded)

@@ -90,7 +90,7 @@ struct nuslam_batch {
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
-    int seq_pub = 0, seq_gather = 0, seq_pred = 0;
+    unsigned seq_pub = 0, seq_gather = 0, seq_pred = 0;   // (sequence words: they wrap, the device compares wrapped differences)
     // Interleaved groups (nuslam_batch_set_interleave): a batch's known-id ticks run as G independent groups of filters, each on
     // a stream of its own, so that one group's HBM-bound pass over P overlaps another group's latency- / VALU-bound chain and
     // strips.  Same kernels on the same per-filter data: same bits.  -1: the library picks (2 for large batches).
@@ -743,15 +743,15 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
             const int n_pred = with_predict ? (h->ld + 255) / 256 : 0;
             TickPublish pub;
-            pub.flag = h->tk_pub; pub.base = h->seq_pub; pub.predict = with_predict ? 1 : 0;
-            pub.gbase = h->seq_gather + 1; pub.pbase = h->seq_pred + n_pred;
+            pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = with_predict ? 1 : 0;
+            pub.gbase = (int)(h->seq_gather + 1u); pub.pbase = (int)(h->seq_pred + (unsigned)n_pred);
             if (with_predict) pub.tw = *fused_predict;
             else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
                                        (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
             if (rc) return rc;
-            h->seq_pub += 2 * kTickJ;
-            if (with_predict) { h->seq_gather += 1; h->seq_pred += n_pred; }
+            h->seq_pub += 2u * kTickJ;
+            if (with_predict) { h->seq_gather += 1u; h->seq_pred += (unsigned)n_pred; }
             rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init, whole(h));
             if (rc) return rc;
         } else {
