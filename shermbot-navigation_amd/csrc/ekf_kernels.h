@@ -240,7 +240,10 @@ __global__ __launch_bounds__(64) void k_associate(View v, ObsArg o, const T* __r
 }
 
 // Stand-alone associateLandmark(): decode the key, publish the id, count a new landmark, re-arm the other slot.
-__global__ void k_associate_finish(View v)
+// host_word (may be null; single-filter API): pinned host memory the answer is ALSO written to -- {id, latched status, expired
+// device-side waits} of filter 0 -- so that the synchronising caller reads it after its stream synchronize without two more
+// blocking copies (the reference's associateLandmark returns the id to the host: one round trip per marker is the API's).
+__global__ void k_associate_finish(View v, int* __restrict__ host_word, const int* __restrict__ expired)
 {
     const int b = blockIdx.x;
     const int* ci = v.c_in + b * C_WORDS;
@@ -250,6 +253,11 @@ __global__ void k_associate_finish(View v)
     co[C_SEEN] = a.new_seen; co[C_SEEN_CACHED] = ci[C_SEEN_CACHED]; co[C_BRK] = ci[C_BRK]; co[C_STATUS] = a.new_status;
     v.akey[2 * b + v.aslot] = kNoKey;         // consumed
     v.akey[2 * b + (v.aslot ^ 1)] = kNoKey;
+    if (host_word && b == 0) {
+        host_word[0] = a.id;
+        host_word[1] = a.new_status;
+        host_word[2] = expired ? *expired : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ init landmark

@@ -63,6 +63,7 @@ struct nuslam_batch {
     int pidx = 0;
     long long p_stride = 0;
     int* cur_id = nullptr;
+    int* host_word = nullptr;  // pinned host memory: {id, status, expired waits} of the last stand-alone associateLandmark
     int* akey = nullptr;       // [B][2] association key slots
     int aslot = 0;
     double* tr = nullptr;      // per-filter trace scratch
@@ -309,7 +310,7 @@ int associate_finish(nuslam_batch* h)
 {
     h->host_seen_valid = false;
     View v = h->view();
-    int rc = launch(h, -1, k_associate_finish, dim3(h->B), dim3(1), v);
+    int rc = launch(h, -1, k_associate_finish, dim3(h->B), dim3(1), v, h->host_word, (const int*)(h->tk_sync ? h->tk_sync + 2 : nullptr));
     if (rc) return rc;
     h->cidx ^= 1;
     h->aslot ^= 1;
@@ -1125,6 +1126,7 @@ void free_batch(nuslam_batch* h)
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->host_word) (void)hipHostFree(h->host_word);
     delete h;
 }
 
@@ -1154,6 +1156,7 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
         HIPCHK(hipMalloc(&h->Pbuf[0], h->esize() * (size_t)B * h->p_stride));
         HIPCHK(hipMalloc(&h->Pbuf[1], h->esize() * (size_t)B * h->p_stride));
         HIPCHK(hipMalloc(&h->cur_id, sizeof(int) * B));
+        HIPCHK(hipHostMalloc((void**)&h->host_word, sizeof(int) * 4, hipHostMallocMapped));
         HIPCHK(hipMalloc(&h->akey, sizeof(int) * 2 * B));
         HIPCHK(hipMalloc(&h->tr, sizeof(double) * B));
         HIPCHK(hipMalloc(&h->stats, sizeof(double) * (2 * h->L + 6)));
@@ -1984,7 +1987,9 @@ int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_
     if (!rc) rc = associate_finish(c);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(id_out, c->cur_id, sizeof(int), hipMemcpyDeviceToHost));
+    // the id, the latched status and the expired-wait count came back through pinned host memory with the kernel itself
+    *id_out = c->host_word[0];
+    if (c->host_word[1] == 0 && c->host_word[2] == 0) return NUSLAM_OK;
     // a full map / singular psi is what the reference reports from inside this very call
     int st = 0;
     rc = read_status(c, 1, nullptr, &st);
