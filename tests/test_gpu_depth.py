@@ -88,6 +88,22 @@ def test_config1_n1000_t200_through_batch_run(hip):
     for k in range(0, len(runs), 2):
         a, b = runs[k][1], runs[k + 1][1]
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov), runs[k][0]
+    # size-independent properties after 3200 corrections, each pass variant beside the oracle: the reference never
+    # symmetrises P (no Joseph form), so asymmetry accumulates at rounding level -- on the GPU as in the oracle; P stays
+    # positive semi-definite to rounding; its trace agrees with the oracle's
+    Po = o.cov
+    scale = np.abs(Po).max()
+    asym_o = float(np.abs(Po - Po.T).max() / scale)
+    for k in range(0, len(runs), 2):
+        Pg = runs[k][1].cov
+        asym = float(np.abs(Pg - Pg.T).max() / scale)
+        lam_min = float(np.linalg.eigvalsh(0.5 * (Pg + Pg.T))[0])
+        dtrace = abs(np.trace(Pg) - np.trace(Po)) / np.trace(Po)
+        print("%s: max|P - P^T| / max|P| = %.1e (oracle %.1e), smallest eigenvalue %.2e (max|P| %.2e), trace vs oracle %.1e"
+              % (runs[k][0].split(",")[0], asym, asym_o, lam_min, scale, dtrace))
+        assert asym < 1e-10 and asym < 100 * max(asym_o, 1e-16)
+        assert lam_min > -1e-10 * scale
+        assert dtrace < 1e-10
 
 
 def test_config3_batch_n200_t100_four_filters(hip):
