@@ -89,7 +89,8 @@ def test_config1_n1000_t200_through_batch_run(hip):
         a, b = runs[k][1], runs[k + 1][1]
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov), runs[k][0]
     # size-independent properties after 3200 corrections, each pass variant beside the oracle: the reference never
-    # symmetrises P (no Joseph form), so asymmetry accumulates at rounding level -- on the GPU as in the oracle; P stays
+    # symmetrises P (no Joseph form) and the snapshot's own asymmetry -- left by the INT_MAX cancellation of the map's
+    # initialisation, ~5e-6 of max|P| -- is carried along: the GPU must carry the SAME asymmetry as the oracle; P stays
     # positive semi-definite to rounding; its trace agrees with the oracle's
     Po = o.cov
     scale = np.abs(Po).max()
@@ -101,7 +102,7 @@ def test_config1_n1000_t200_through_batch_run(hip):
         dtrace = abs(np.trace(Pg) - np.trace(Po)) / np.trace(Po)
         print("%s: max|P - P^T| / max|P| = %.1e (oracle %.1e), smallest eigenvalue %.2e (max|P| %.2e), trace vs oracle %.1e"
               % (runs[k][0].split(",")[0], asym, asym_o, lam_min, scale, dtrace))
-        assert asym < 1e-10 and asym < 100 * max(asym_o, 1e-16)
+        assert abs(asym - asym_o) < 1e-9 * max(asym_o, 1e-7) + 1e-12
         assert lam_min > -1e-10 * scale
         assert dtrace < 1e-10
 
