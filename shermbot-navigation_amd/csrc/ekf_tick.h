@@ -32,6 +32,17 @@
 // Every floating-point operation on every element is the one k_update performs, in the same order, with the same
 // rounding to the storage type after each correction; only where it is executed has changed.  The result is therefore
 // bit-identical to m launches of k_update (tests/test_gpu_tick.py) and hence to the oracle's update().
+//
+// Round 3, on top of that:
+//   k_tick_rank    (ekf_rank.h) the DEFAULT pass over P: the same product re-associated as a rank-2m update on the matrix
+//                  cores, P -= [K_1 .. K_m][V_1; ..; V_m] with V_s = H_s R_s formed beside R_s (hp_entry) -- 2 FMAs per
+//                  element and correction instead of 7, a streaming kernel; agrees with the chain above to rounding, not bit
+//                  for bit.  Rounds that cancel an INT_MAX diagonal stay with k_tick_apply (round_flags; the plan's `init`).
+//   k_tick_front   one filter: predict, chain and strips as ONE launch.  The chain (workgroup 0) gathers its block from the
+//                  covariance before predict and applies predict to it itself (predict_block); the predict workgroups
+//                  rewrite rows / columns 1, 2 of P; the strip workgroups follow the chain entry by entry as it announces
+//                  each plan entry (TickPublish: agent-scope stores and loads, no fences) instead of starting when it ends.
+//                  Same arithmetic as k_predict + k_tick_chain + k_tick_panels: same bits.
 #pragma once
 
 namespace nuslam {
