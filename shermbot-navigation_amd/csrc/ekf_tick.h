@@ -445,7 +445,6 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     __shared__ double zr[kTickJ], zphi[kTickJ];   // the markers in polar form (slam.cpp:286)
     __shared__ double hd[20];                     // Hc[10], Sinv[4], lx, ly, dz0, dz1, z_hat range, un-rotated bearing
     __shared__ int hi[2];
-    __shared__ int hflag;                         // st + 1 once wave 1 has put correction st's H into hd[0..9]
     __shared__ int Ush[NU + 1];
     __shared__ int idsh[kTickJ];
 
@@ -458,7 +457,6 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         Ush[4 + 2 * tid] = c + 1;
     }
     if (tid < 3) Ush[tid] = tid;
-    if (tid == 0) hflag = 0;
     __syncthreads();
     int seen = 0, brk = 0, status = 0, cached = 0;
     if (FUSED) {
@@ -595,37 +593,18 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 for (int q = 0; q < 5; ++q)
 #pragma unroll
                     for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);   // pb[q][q2] = P(set[q2], set[q])
-                // H comes from wave 1 (its sqrt and four divisions ran beside the entries above): an LDS word says it is there.
-                // (A wave's LDS accesses execute in order: wave 1 writes H, then the word; this wave reads the word, then H.)
-                {
-                    int seen_flag;
-                    do {
-                        seen_flag = *reinterpret_cast<volatile int*>(&hflag);
-                    } while (seen_flag != st + 1);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 10; ++q) Hc[q] = *reinterpret_cast<volatile double*>(&hd[q]);
+                jacobian_compact(x, y, lx, ly, Hc);                     // :268
                 innovation_cov_block(pb, Hc, v.R, S);                   // H P H^T + R, :270
                 const int sing = inv2(S, Si);
                 if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) hd[q] = Hc[q];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hd[10 + q] = Si[q];
                     hd[14] = lx; hd[15] = ly;
                     hi[0] = sing;
                 }
             } else {
-                // the Jacobian (:268) first, for the head wave: one sqrt and four divisions that used to sit on ITS chain
-                {
-                    double Hc[10];
-                    jacobian_compact(x, y, lx, ly, Hc);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) hd[q] = Hc[q];
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) *reinterpret_cast<volatile int*>(&hflag) = st + 1;
-                }
                 const double mx = lx - x, my = ly - y;                  // measurement(): :152-156
                 double zr_h, zb_h;
                 cartesian2polar(mx, my, zr_h, zb_h);
