@@ -443,7 +443,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     __shared__ double SM[2][NU + 1];              // state at U
     __shared__ double MPl[2][NU][8];              // M at the rows of U: of the correction in flight / of the one whose block update is pending
     __shared__ double zr[kTickJ], zphi[kTickJ];   // the markers in polar form (slam.cpp:286)
-    __shared__ double hd[20];                     // Hc[10], Sinv[4], lx, ly, dz0, dz1, z_hat range, un-rotated bearing
+    __shared__ double hd[2][20];                  // Hc[10], Sinv[4], lx, ly, dz0, dz1 of the correction whose head is being formed / was formed last
     __shared__ int hi[2];
     __shared__ int Ush[NU + 1];
     __shared__ int idsh[kTickJ];
@@ -499,21 +499,29 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     }
     __syncthreads();
 
-    // The block update of correction s is DEFERRED into the first phase of correction s+1, where it runs on waves 0, 2, 3
-    // in the shadow of wave 1's transcendental chain (the polar form of the next landmark offset needs the state, not
-    // the block).  Wave 2 forms the 25 entries the next head needs itself, with the same formula.
+    // ONE phase (one workgroup barrier) per correction.  Between the barrier that ends the head of correction s-1 and the
+    // one that ends the head of correction s, every wave works from the same three things -- the block and the state BEFORE
+    // correction s-1 (BK[bcur], SM[scur]) and that correction's head (H, S^-1, innovation: hd[hb]) -- and forms for itself
+    // whatever it needs of what correction s-1 leaves:
+    //   wave 2  the rows of M_{s-1} and the state at set_s (five gain rows), with them the 25 entries P_{s-1}(set_s, set_s)
+    //           (p1_entry, the block update's own formula), then H_s, S_s, S_s^-1                    -> hd[hb ^ 1]
+    //   wave 1  the prior rows and the scalars of correction s-1 to the plan; the state at set_s likewise, the polar form of the
+    //           landmark offset and the innovation of correction s                                     -> hd[hb ^ 1]
+    //   wave 0  K, M at all rows of U and the state there after correction s-1 (the plan's MP rows), a third of the block update
+    //   wave 3  the rows of M once more (its own copy), two thirds of the block update
+    // (Until round 3 the gain rows had a phase of their own between head and head: 0.55 us and a barrier per correction on
+    // the critical path; now only the head is on it.)  The arithmetic of every value is unchanged.
     auto advance_entry = [&](const double (*Bo)[NU + 1], const double (*Mp)[8], const int spP[5], int p, int pp) {
         double mrow[5], r[5];
 #pragma unroll
         for (int q = 0; q < 5; ++q) { mrow[q] = Mp[p][q]; r[q] = Bo[spP[q]][pp]; }
         return p1_entry<T>(mrow, r, Bo[p][pp], Mp[p][5], Mp[p][6]);
     };
-    // entries of the deferred update: shared by the 192 lanes of waves 0, 2, 3 (or by all 256 in the serial path)
+    // the block update: 192 slots (wave 0 one, wave 3 two)
     auto run_pending = [&](const double (*Bo)[NU + 1], double (*Bn)[NU + 1], const double (*Mp)[8], int posP, int me) {
         // only the rows / columns a later correction still reads: positions 0, 1, 2 and those behind marker posP (the
         // same liveness as in the strips), walked as a 16 x 12 thread grid over the live index list -- no division
         const int spP[5] = { 0, 1, 2, posP, posP + 1 };
-        if (me < 0) return;
         const int nl = 3 + (NU - (posP + 2));
         const int ty = me / 12, tx = me - 12 * ty;
         for (int a = ty; a < nl; a += 16) {
@@ -524,17 +532,202 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             }
         }
     };
-    int bcur = 0, scur = 0, mb = 0;
-    bool pend = false;                    // BK[bcur] still lacks the update of correction `last_live` (MPl[mb], position pend_pos)
-    int pend_pos = 3;
-    bool theta_raw = false;               // SM[scur][0] holds theta + K nu of the previous correction, not yet wrapped
-    int last_live = 0;                    // that correction
+    int bcur = 0, scur = 0, hb = 0;
+    bool have = false;                    // correction pv_* has its head in hd[hb]; its gain rows, state and block update are pending
+    int pv_st = 0, pv_pos = 3, pv_c = 3, pv_id = 0;
+    bool pv_init = false;
 #ifdef NUSLAM_CHAIN_CLOCK
     long long ck[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ct = (long long)wall_clock64();
 #define CK(k) do { const long long n__ = (long long)wall_clock64(); ck[k] += n__ - ct; ct = n__; } while (0)
 #else
 #define CK(k) do { } while (0)
 #endif
+    // one phase: what correction pv leaves (if `have`), and the head of correction st (if has_cur)
+    auto phase = [&](const bool has_cur, const int st, const bool cur_init) {
+        const double (*B0)[NU + 1] = BK[bcur];                          // the block before correction pv, complete
+        const double* S0 = SM[scur];
+        const double* hP = hd[hb];
+        double* hN = hd[hb ^ 1];
+        const int posP = pv_pos, cP = pv_c;
+        const int spP[5] = { 0, 1, 2, posP, posP + 1 };                 // positions of set_pv in U
+        const int setP[5] = { 0, 1, 2, cP, cP + 1 };
+        TickStep* psP = pl + pv_st;
+        // K, M of correction pv at row U[p] and the state there after it (slam_library.cpp:271-275; the heading still raw)
+        auto row_after = [&](int p, double m[5], double& bef, double& aft) {
+            const int i = Ush[p];
+            double pc[5], Hc[10], Si[4], KP[2];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pc[q] = B0[p][spP[q]];          // P(U[p], set[q])
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = hP[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si[q] = hP[10 + q];
+            gain_row(pc, Hc, Si, i, setP, KP, m);
+            bef = (i > 2 && i < cP) ? 1.0 : 0.0;
+            aft = (i > cP + 1) ? 1.0 : 0.0;
+            double sv = (pv_init && i == cP) ? hP[14] : (pv_init && i == cP + 1) ? hP[15] : S0[p];
+            double acc = 0.0;
+            acc = fma(KP[0], hP[16], acc);
+            acc = fma(KP[1], hP[17], acc);
+            return sv + acc;                                            // :275
+        };
+        const int pos = 3 + 2 * st;
+        const int sp[5] = { 0, 1, 2, pos, pos + 1 };                    // positions of set_st in U
+        if (wave == 0) {
+            if (have) {
+                if (lane < NU) {
+                    const int p = lane;
+                    double m[5], bef, aft;
+                    double sv = row_after(p, m, bef, aft);
+                    double (*Mn)[8] = MPl[0];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; if (!PUBLISH) psP->MP[p][q] = m[q]; }
+                    Mn[p][5] = bef; Mn[p][6] = aft;
+                    if (!PUBLISH) {                                     // (the strip workgroups of k_tick_front form the two flags themselves)
+                        psP->MP[p][5] = bef; psP->MP[p][6] = aft;
+                        if (p > 0) psP->MP[p][7] = 0.0;
+                    }
+                    if (p == 0) {                                       // the heading row after that correction, wrapped (:276)
+                        sv = normalize_angle(sv);
+                        plan_store(PUBLISH, &psP->MP[0][7], sv);
+                    }
+                    SM[scur ^ 1][p] = sv;
+                }
+                if (PUBLISH) {
+                    // the rows of M to the plan, COALESCED: lane l of store k writes word 64 k + l of MP (rows of 8 words), read
+                    // back from the LDS copy this wave has just written (a wave's LDS accesses execute in order).  With one row
+                    // per lane every store instruction touched 35 different cache lines through the CU's one address path.
+                    const double (*Mr)[8] = MPl[0];
+#pragma unroll
+                    for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
+                        const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
+                        if (p < NU && q < 5) st_agent(&psP->MP[0][0] + idx, Mr[p][q]);
+                    }
+                }
+                if (has_cur) run_pending(B0, BK[bcur ^ 1], MPl[0], posP, lane);
+            }
+        } else if (wave == 3) {
+            if (have && has_cur) {
+                if (lane < NU) {
+                    double m[5], bef, aft;
+                    (void)row_after(lane, m, bef, aft);
+                    double (*Mn)[8] = MPl[1];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) Mn[lane][q] = m[q];
+                    Mn[lane][5] = bef; Mn[lane][6] = aft;
+                }
+                run_pending(B0, BK[bcur ^ 1], MPl[1], posP, 64 + lane);
+                run_pending(B0, BK[bcur ^ 1], MPl[1], posP, 128 + lane);
+            }
+        } else {
+            if (wave == 1 && have) {
+                // the plan entry of correction pv: the five prior rows at the columns of U and the scalars -- issued first, so that
+                // the wait for them in front of the barrier finds them acknowledged
+                const int fresh = B0[posP][posP] > 1.0e9 ? 2 : 0;       // INT_MAX (2.1e9) still on the landmark's diagonal
+                if (PUBLISH) {
+#pragma unroll
+                    for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
+                        const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
+                        if (p < NU && q < 5) st_agent(&psP->BR[0][0] + idx, B0[spP[q]][p]);
+                    }
+                    // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4],
+                    // dz[2], lxy[2], contiguous behind them
+                    const int w = lane;
+                    if (w < 20) {
+                        long long word;
+                        if (w == 0) word = (long long)(unsigned)0 | ((long long)((pv_init ? 1 : 0) | fresh) << 32);
+                        else if (w == 1) word = (long long)(unsigned)cP | ((long long)pv_id << 32);
+                        else {
+                            const int f = w - 2;                        // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz = hd[16], hd[17]; 16, 17: lxy = hd[14], hd[15]
+                            word = __double_as_longlong(hP[f < 14 ? f : (f < 16 ? f + 2 : f - 2)]);
+                        }
+                        st_agent(reinterpret_cast<long long*>(psP) + w, word);
+                    }
+                } else {
+                    if (lane < NU) {
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) psP->BR[lane][q] = B0[spP[q]][lane];
+                    }
+                    if (lane == 0) {
+                        plan_store_head(false, psP, 0, (pv_init ? 1 : 0) | fresh, cP, pv_id);
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) psP->Hc[q] = hP[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) psP->Sinv[q] = hP[10 + q];
+                        psP->dz[0] = hP[16]; psP->dz[1] = hP[17]; psP->lxy[0] = hP[14]; psP->lxy[1] = hP[15];
+                    }
+                }
+            }
+            if (has_cur) {
+                // the state at set_st after correction pv: lane j (mod 5) forms the row of position sp[j]
+                const int j = lane % 5, p = sp[j];
+                double m[5], bef = 0.0, aft = 0.0, sv;
+                CK(2);
+                if (have) sv = row_after(p, m, bef, aft);
+                else sv = S0[p];
+                CK(3);
+                const double th_raw = lane_bcast(sv, 0), x = lane_bcast(sv, 1), y = lane_bcast(sv, 2);
+                double lx, ly;
+                if (cur_init) {                                         // initializeLandmark, slam_library.cpp:255-261: wrapped heading
+                    const double th = have ? normalize_angle(th_raw) : th_raw, r = zr[st], phi = zphi[st];
+                    lx = x + r * cos(phi + th);
+                    ly = y + r * sin(phi + th);
+                } else { lx = lane_bcast(sv, 3); ly = lane_bcast(sv, 4); }
+                if (wave == 2) {
+                    // P(set[q2], set[q]) after correction pv: one entry per lane (lane e = 5 q + q2 holds the row of M it needs:
+                    // q2 == j), then broadcast
+                    double ent;
+                    {
+                        const int e = lane < 25 ? lane : j;
+                        const int q = e / 5, q2 = e % 5;
+                        const double pij = B0[sp[q2]][sp[q]];
+                        if (have) {
+                            double r[5];
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) r[k] = B0[spP[k]][sp[q]];
+                            ent = p1_entry<T>(m, r, pij, bef, aft);
+                        } else ent = pij;
+                    }
+                    CK(4);
+                    double Hc[10], S[4], Si[4], pb[5][5];
+#pragma unroll
+                    for (int q = 0; q < 5; ++q)
+#pragma unroll
+                        for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);   // pb[q][q2] = P(set[q2], set[q])
+                    jacobian_compact(x, y, lx, ly, Hc);                 // :268
+                    CK(5);
+                    innovation_cov_block(pb, Hc, v.R, S);               // H P H^T + R, :270
+                    CK(6);
+                    const int sing = inv2(S, Si);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int q = 0; q < 10; ++q) hN[q] = Hc[q];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hN[10 + q] = Si[q];
+                        hN[14] = lx; hN[15] = ly;
+                        hi[hb ^ 1] = sing;
+                    }
+                } else {
+                    const double mx = lx - x, my = ly - y;              // measurement(): :152-156
+                    double zr_h, zb_h;
+                    cartesian2polar(mx, my, zr_h, zb_h);
+                    CK(4);
+                    // ... and the innovation, against the WRAPPED heading (:157-159, :276)
+                    const double th_w = normalize_angle(th_raw);
+                    const double zb = normalize_angle(zb_h - th_w);
+                    if (lane == 0) { hN[16] = zr[st] - zr_h; hN[17] = zphi[st] - zb; }   // :272, bearing not wrapped
+                }
+            }
+        }
+        // (PUBLISH: the stores of entry pv -- wave 0's rows of M and heading, wave 1's prior rows and scalars, issued at the top
+        // of this phase -- are waited for here)
+        if (PUBLISH && (wave == 0 || wave == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CK(0);
+        lds_barrier();
+        CK(1);
+        if (have) { scur ^= 1; bcur ^= 1; }
+        hb ^= 1;
+    };
     for (int st = 0; st < J; ++st) {
         CK(7);
         const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
@@ -546,103 +739,12 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             continue;
         }
         const int pos = 3 + 2 * st, c = d.c;
-        const int sp[5] = { 0, 1, 2, pos, pos + 1 };                    // positions of set_s in U
-        const int setv[5] = { 0, 1, 2, c, c + 1 };
-
-        if (d.init) {
-            // A first sighting needs the wrapped heading before anything else (initializeLandmark, :255-261): serial path
-            if (wave == 0 && theta_raw) {
-                const double th = normalize_angle(SM[scur][0]);
-                if (lane == 0) { SM[scur][0] = th; plan_store(PUBLISH, &pl[last_live].MP[0][7], th); }
-            }
-            if (pend) run_pending(BK[bcur], BK[bcur ^ 1], MPl[mb], pend_pos, wave == 0 ? -1 : tid - 64);
-            lds_barrier();
-            if (pend) { bcur ^= 1; pend = false; }
-            theta_raw = false;
-        }
-        const double (*Bo)[NU + 1] = BK[bcur];                          // the block before the pending update (if any)
-        const double* S0 = SM[scur];
-
-        // ---- phase 1: heading re-normalisation (wave 0) | polar form of the landmark offset (wave 1) | H, S, S^-1
-        // (wave 2) | the deferred block update (waves 0, 2, 3)
-        if (wave == 0 && theta_raw) {
-            const double th = normalize_angle(SM[scur][0]);
-            if (lane == 0) { SM[scur][0] = th; plan_store(PUBLISH, &pl[last_live].MP[0][7], th); }   // the heading row after that correction (:276)
-        }
-        if (wave == 1 || wave == 2) {
-            const double x = S0[1], y = S0[2];
-            double lx, ly;
-            if (d.init) {                                               // initializeLandmark, slam_library.cpp:255-261
-                const double th = S0[0], r = zr[st], phi = zphi[st];
-                lx = x + r * cos(phi + th);
-                ly = y + r * sin(phi + th);
-            } else { lx = S0[pos]; ly = S0[pos + 1]; }
-            if (wave == 2) {
-                // P(set[q2], set[q]) after the pending update: formed here, one entry per lane, then broadcast
-                double ent = 0.0;
-                {
-                    const int e = lane < 25 ? lane : 0;
-                    const int q = e / 5, q2 = e % 5;
-                    if (pend) {
-                        const int spP[5] = { 0, 1, 2, pend_pos, pend_pos + 1 };
-                        ent = advance_entry(Bo, MPl[mb], spP, sp[q2], sp[q]);
-                    } else ent = Bo[sp[q2]][sp[q]];
-                }
-                double Hc[10], S[4], Si[4], pb[5][5];
-#pragma unroll
-                for (int q = 0; q < 5; ++q)
-#pragma unroll
-                    for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);   // pb[q][q2] = P(set[q2], set[q])
-                jacobian_compact(x, y, lx, ly, Hc);                     // :268
-                innovation_cov_block(pb, Hc, v.R, S);                   // H P H^T + R, :270
-                const int sing = inv2(S, Si);
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) hd[q] = Hc[q];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) hd[10 + q] = Si[q];
-                    hd[14] = lx; hd[15] = ly;
-                    hi[0] = sing;
-                }
-            } else {
-                const double mx = lx - x, my = ly - y;                  // measurement(): :152-156
-                double zr_h, zb_h;
-                cartesian2polar(mx, my, zr_h, zb_h);
-                // ... and the innovation, against the WRAPPED heading (:157-159, :276).  Wave 0 is wrapping it in this very
-                // phase; this wave wraps its own copy (a range reduction: same bits, and idempotent should it read the
-                // already wrapped word), so that nothing of the innovation is left for the phase behind the barrier
-                const double th_w = normalize_angle(S0[0]);
-                const double zb = normalize_angle(zb_h - th_w);
-                if (lane == 0) { hd[16] = zr[st] - zr_h; hd[17] = zphi[st] - zb; }       // :272, bearing not wrapped
-            }
-        }
-        if (pend) {
-            // measured per correction (wave clock): head 1.05 us on wave 2, heading 0.6 us on wave 0, polar form 1.0 us on
-            // wave 1 -- so wave 3 takes two thirds of the deferred update, wave 0 the rest, wave 2 none
-            if (wave == 0) run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, lane);
-            else if (wave == 3) {
-                run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, 64 + lane);
-                run_pending(Bo, BK[bcur ^ 1], MPl[mb], pend_pos, 128 + lane);
-            }
-        }
-        theta_raw = false;
-        // (PUBLISH: the stores of the previous entry -- wave 0's rows of M and wave 2's prior rows and scalars a correction ago,
-        // the wrapped heading at the top of this phase -- are waited for here: they are > 1 us old)
-        if (PUBLISH && (wave == 0 || wave == 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CK(0);
-        lds_barrier();
-        CK(1);
-        if (pend) { bcur ^= 1; pend = false; }
-        const double (*B0)[NU + 1] = BK[bcur];                          // the block before THIS correction, complete
-        const int fresh = B0[pos][pos] > 1.0e9 ? 2 : 0;                 // INT_MAX (2.1e9) still on the landmark's diagonal
-
-        // ---- phase 2: K, M at the rows of U and the state there (wave 0) | the prior rows at the columns of U and the plan's
-        // scalars (wave 2).  (The innovation used to be formed here by wave 1 and the state in a third phase behind one more
-        // barrier; with the wraps a range reduction it fits into phase 1, and the state follows the gain rows at once.)
-        const double lx = hd[14], ly = hd[15];
-        const bool sing = hi[0] != 0;
-        const double dz0 = hd[16], dz1 = hd[17];                        // z - z_hat, formed by wave 1 in phase 1
-        if (sing) {                                                     // singular S: update() throws after the init
+        phase(true, st, d.init);
+        // entries 0 .. st-1 are complete: waves 0 and 1 waited for their stores in front of the barrier just passed
+        if (PUBLISH && tid == 192) st_agent(pub.flag + kPubWords * b, (int)((unsigned)pub.base + (unsigned)st));
+        if (hi[hb] != 0) {                                              // singular S: update() throws after the init
+            const double lx = hd[hb][14], ly = hd[hb][15];
+            const int fresh = BK[bcur][pos][pos] > 1.0e9 ? 2 : 0;
             if (status == 0) status = kStatusSingular;
             if (tid == 0) {
                 plan_store_head(PUBLISH, ps, 1, (d.init ? 1 : 0) | fresh, c, d.id);
@@ -653,106 +755,18 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 if (i == c) SM[scur][tid] = lx;
                 if (i == c + 1) SM[scur][tid] = ly;
             }
-            CK(2);
             lds_barrier();
-            CK(3);
+            have = false;
             continue;
         }
-        if (tid < NU) {
-            const int p = tid, i = Ush[p];
-            double pc[5], Hc[10], Si[4], m[5], KP[2];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) pc[q] = B0[p][sp[q]];          // P(U[p], set[q])
-#pragma unroll
-            for (int q = 0; q < 10; ++q) Hc[q] = hd[q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Si[q] = hd[10 + q];
-            gain_row(pc, Hc, Si, i, setv, KP, m);
-            const double bef = (i > 2 && i < c) ? 1.0 : 0.0, aft = (i > c + 1) ? 1.0 : 0.0;
-            double (*Mn)[8] = MPl[mb ^ 1];
-#pragma unroll
-            for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; if (!PUBLISH) ps->MP[p][q] = m[q]; }
-            Mn[p][5] = bef; Mn[p][6] = aft;
-            if (!PUBLISH) {                                             // (the strip workgroups of k_tick_front form the two flags themselves)
-                ps->MP[p][5] = bef; ps->MP[p][6] = aft;
-                if (p > 0) ps->MP[p][7] = 0.0;                          // (MP[0][7]: the wrapped heading, written when it is formed)
-            }
-            // the state at U
-            double sv = (d.init && i == c) ? lx : (d.init && i == c + 1) ? ly : S0[p];
-            double acc = 0.0;
-            acc = fma(KP[0], dz0, acc);
-            acc = fma(KP[1], dz1, acc);
-            sv = sv + acc;                                              // :275 (the heading stays raw until it is next read)
-            SM[scur ^ 1][p] = sv;
-        }
-        if (PUBLISH && wave == 0) {
-            // the rows of M to the plan, COALESCED: lane l of store k writes word 64 k + l of MP (rows of 8 words), read back
-            // from the LDS copy this wave has just written (a wave's LDS accesses execute in order).  With one row per lane
-            // every store instruction touched 35 different cache lines through the CU's one address path: 0.25 us of the phase.
-            const double (*Mr)[8] = MPl[mb ^ 1];
-#pragma unroll
-            for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
-                const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
-                if (p < NU && q < 5) st_agent(&ps->MP[0][0] + idx, Mr[p][q]);
-            }
-        } else if (wave == 2) {
-            if (PUBLISH) {                                              // the five prior rows at the columns of U, coalesced likewise
-#pragma unroll
-                for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
-                    const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
-                    if (p < NU && q < 5) st_agent(&ps->BR[0][0] + idx, B0[sp[q]][p]);
-                }
-            } else if (tid < 128 + NU) {
-                const int p = tid - 128;
-#pragma unroll
-                for (int q = 0; q < 5; ++q) ps->BR[p][q] = B0[sp[q]][p];
-            }
-            if (PUBLISH) {
-                // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4],
-                // dz[2], lxy[2], contiguous behind them (a single lane storing twenty agent-scope words one after the other
-                // cost 0.4 us)
-                const int w = lane;
-                if (w < 20) {
-                    long long word;
-                    if (w == 0) word = (long long)(unsigned)0 | ((long long)((d.init ? 1 : 0) | fresh) << 32);
-                    else if (w == 1) word = (long long)(unsigned)c | ((long long)d.id << 32);
-                    else {
-                        const int f = w - 2;                            // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz; 16, 17: lxy = hd[14], hd[15]
-                        word = __double_as_longlong(f < 14 ? hd[f] : (f == 14 ? dz0 : (f == 15 ? dz1 : hd[f - 2])));
-                    }
-                    st_agent(reinterpret_cast<long long*>(ps) + w, word);
-                }
-            } else if (tid == 128) {
-                plan_store_head(false, ps, 0, (d.init ? 1 : 0) | fresh, c, d.id);
-#pragma unroll
-                for (int q = 0; q < 10; ++q) ps->Hc[q] = hd[q];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ps->Sinv[q] = hd[10 + q];
-                ps->dz[0] = dz0; ps->dz[1] = dz1; ps->lxy[0] = lx; ps->lxy[1] = ly;
-            }
-        } else if (PUBLISH && tid == 192) {
-            // entries 0 .. st-1 are complete: waves 0 and 2 waited for their stores at the end of phase 1, in front of the
-            // barrier just passed
-            st_agent(pub.flag + kPubWords * b, (int)((unsigned)pub.base + (unsigned)st));
-        }
-        CK(2);
-        lds_barrier();
-        CK(3);
-        scur ^= 1;
-        mb ^= 1;
-        pend = true;
-        pend_pos = pos;
-        theta_raw = true;
-        last_live = st;
+        have = true;
+        pv_st = st; pv_pos = pos; pv_c = c; pv_id = d.id; pv_init = d.init;
     }
+    if (have) phase(false, 0, false);                                   // what the last correction leaves: its plan entry
 #ifdef NUSLAM_CHAIN_CLOCK
     if (lane == 0 && b == 0)
         for (int k = 0; k < 8; ++k) g_chain_clock[wave * 8 + k] = ck[k];
 #endif
-    if (theta_raw && wave == 0) {                                       // the heading after the last correction
-        const double th = normalize_angle(SM[scur][0]);
-        if (lane == 0) plan_store(PUBLISH, &pl[last_live].MP[0][7], th);
-    }
     if (PUBLISH) {                                                      // the whole round is complete
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -20,6 +20,8 @@ for t in range(30, 40):
     bt.run(t, t + 1); bt.sync()
     out = (C.c_longlong * 32)(); L.nuslam_debug_chain_clock(out); acc.append(list(out))
 a = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8) * 0.01 / m   # us per step
-names = ["phase 1", "barrier 1", "phase 2", "barrier 2", "phase 3", "barrier 3", "-", "loop top"]
+# stamps inside the one phase of a correction (ekf_tick.h, CK(k)): waves 1, 2: [2] plan stores (wave 1), [3] gain rows at set_s,
+# [4] wave 2: the 25 entries / wave 1: landmark offset in polar form, [5] broadcasts + Jacobian, [6] S, [0] rest up to the barrier
+names = ["rest", "barrier", "stores", "rows", "entries|polar", "bcast+H", "S", "loop top"]
 for w in range(4):
-    print("wave %d: " % w + ", ".join("%s %.2f" % (names[k], a[w, k]) for k in (7, 0, 1, 2, 3, 4, 5)) + "  | sum %.2f us/step" % a[w].sum())
+    print("wave %d: " % w + ", ".join("%s %.2f" % (names[k], a[w, k]) for k in (7, 2, 3, 4, 5, 6, 0, 1)) + "  | sum %.2f us/step" % a[w].sum())
