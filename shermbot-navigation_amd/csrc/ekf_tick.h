@@ -538,7 +538,9 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     bool pv_init = false;
 #ifdef NUSLAM_CHAIN_CLOCK
     long long ck[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ct = (long long)wall_clock64();
-#define CK(k) do { const long long n__ = (long long)wall_clock64(); ck[k] += n__ - ct; ct = n__; } while (0)
+// (a stamp costs ~0.05 us and pins the code around it: with NUSLAM_CHAIN_CLOCK == 1 only the two around the barrier are taken --
+// busy time per wave --, with 2 all of them)
+#define CK(k) do { if (NUSLAM_CHAIN_CLOCK > 1 || (k) < 2) { const long long n__ = (long long)wall_clock64(); ck[k] += n__ - ct; ct = n__; } } while (0)
 #else
 #define CK(k) do { } while (0)
 #endif
@@ -728,6 +730,9 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         if (have) { scur ^= 1; bcur ^= 1; }
         hb ^= 1;
     };
+#ifdef NUSLAM_CHAIN_CLOCK
+    const long long sclk0 = (long long)clock64(), wclk0 = (long long)wall_clock64();
+#endif
     for (int st = 0; st < J; ++st) {
         CK(7);
         const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
@@ -764,6 +769,10 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     }
     if (have) phase(false, 0, false);                                   // what the last correction leaves: its plan entry
 #ifdef NUSLAM_CHAIN_CLOCK
+    if (wave == 3) {                                                    // shader cycles per 100 MHz tick over the loop: the clock the CU ran at
+        ck[2] = (long long)clock64() - sclk0;
+        ck[3] = (long long)wall_clock64() - wclk0;
+    }
     if (lane == 0 && b == 0)
         for (int k = 0; k < 8; ++k) g_chain_clock[wave * 8 + k] = ck[k];
 #endif

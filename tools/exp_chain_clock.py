@@ -11,7 +11,9 @@ tr = synth.make_trace(n, 40, m)
 bx, by, wid = synth.warmup_observations(tr.landmarks)
 ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT)
 ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
-bt = ekf.as_batch(); bt.set_tick_mode(1)
+bt = ekf.as_batch()
+if os.environ.get("CHAIN_ONLY"):
+    bt.set_tick_mode(1)        # k_tick_chain as a launch of its own (plain plan stores) instead of k_tick_front's workgroup 0
 bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
 bt.run(0, 30); bt.sync()
 L = nh.lib(); L.nuslam_debug_chain_clock.argtypes = [C.POINTER(C.c_longlong)]
@@ -19,7 +21,10 @@ acc = []
 for t in range(30, 40):
     bt.run(t, t + 1); bt.sync()
     out = (C.c_longlong * 32)(); L.nuslam_debug_chain_clock(out); acc.append(list(out))
-a = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8) * 0.01 / m   # us per step
+raw = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8)
+print("shader clock over the loop: %.0f MHz (%d cycles in %.2f us)" % (100.0 * raw[3, 2] / raw[3, 3], raw[3, 2], raw[3, 3] * 0.01))
+raw[3, 2] = raw[3, 3] = 0
+a = raw * 0.01 / m   # us per step
 # stamps inside the one phase of a correction (ekf_tick.h, CK(k)): waves 1, 2: [2] plan stores (wave 1), [3] gain rows at set_s,
 # [4] wave 2: the 25 entries / wave 1: landmark offset in polar form, [5] broadcasts + Jacobian, [6] S, [0] rest up to the barrier
 names = ["rest", "barrier", "stores", "rows", "entries|polar", "bcast+H", "S", "loop top"]
