@@ -396,7 +396,11 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
 
 // ------------------------------------------------------------------------------------------------ the serial chain
 #ifdef NUSLAM_CHAIN_CLOCK
+__device__ long long g_front_tl[16];          // debug builds: absolute 100 MHz stamps of one k_tick_front launch (TL below)
+#define TL(k, cond) do { if (cond) g_front_tl[k] = (long long)wall_clock64(); } while (0)
 __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
+#else
+#define TL(k, cond) do { } while (0)
 #endif
 // FUSED: the workgroup first waits for the previous tick's strips, replays that tick's corrections on the 35 x 35 block
 // (what used to be a kernel of its own, k_tick_next: ~5 us of launch and one more hand-off per tick on the critical path
@@ -438,6 +442,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     const T* Pb = P + (size_t)b * v.p_stride;
     TickStep* pl = plan + (size_t)b * kTickJ;
     const int J = o.J;
+    TL(0, PUBLISH && b == 0 && tid == 0);                               // chain: entry
 
     __shared__ double BK[2][NU][NU + 1];          // P(U[p], U[p']) before / after the current correction
     __shared__ double SM[2][NU + 1];              // state at U
@@ -447,6 +452,8 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     __shared__ int hi[2];
     __shared__ int Ush[NU + 1];
     __shared__ int idsh[kTickJ];
+    __shared__ int4 dlive[kTickJ + 1];            // the corrections that change P, in order: { marker, first state index, resolved id, init }
+    __shared__ int dsum[4];                       // landmarks seen / break flag after the round, first marker with a bounds error, live count
 
     if (tid < kTickJ) {
         int id = 0;
@@ -497,7 +504,38 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         zr[lane] = r;
         zphi[lane] = phi;
     }
+    if (wave == 2) {
+        // The caller's decision chain for every marker of the round (slam.cpp:295-316), once, one lane per marker, beside the
+        // polar forms: it depends on the ids and the counters only (a singular S changes the status word, nothing else), so the
+        // loop below walks a list of live corrections and has no decision on its critical path.  What one marker hands to the
+        // next is the break flag (set by the first marker that takes the branch of :301-316; which one does not depend on
+        // it) and the running maximum of `seen`, which no decision reads.  Markers that change nothing get their plan entry here.
+        const int st = lane;
+        const bool in = st < J;
+        const int id_st = in ? idsh[st] : 0;
+        const Decision d0 = resolve(v.n, id_st, seen, cached, brk, 0, MODE_KNOWN, total_landmarks);   // with the round's incoming break flag
+        const unsigned long long brk_set = __ballot(in && d0.new_brk != 0 && brk == 0);
+        const bool brk_here = brk != 0 || (brk_set & ((1ull << st) - 1ull)) != 0ull;
+        const Decision d = resolve(v.n, id_st, seen, cached, brk_here ? 1 : 0, 0, MODE_KNOWN, total_landmarks);
+        const unsigned long long live = __ballot(in && !d.skip), bad = __ballot(in && d.new_status != 0);
+        int smax = in ? d.new_seen : seen;                              // (new_seen = max(seen, id) where the marker counts)
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) smax = max(smax, __shfl_xor(smax, off, 64));
+        if (in) {
+            if (v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = d.id;
+            if (d.skip) plan_store_head(PUBLISH, pl + st, 1, 0, 3, d.id);
+            else dlive[__popcll(live & ((1ull << st) - 1ull))] = make_int4(st, d.c, d.id, d.init ? 1 : 0);
+        }
+        if (lane == 0) {
+            const int nl = __popcll(live);
+            dlive[nl] = make_int4(0, 3, 0, 0);
+            dsum[0] = smax; dsum[1] = (brk != 0 || brk_set != 0ull) ? 1 : 0;
+            dsum[2] = bad ? __ffsll((long long)bad) - 1 : 255; dsum[3] = nl;
+        }
+    }
     __syncthreads();
+    seen = dsum[0]; brk = dsum[1];
+    const int nlive = dsum[3];
 
     // ONE phase (one workgroup barrier) per correction.  Between the barrier that ends the head of correction s-1 and the
     // one that ends the head of correction s, every wave works from the same three things -- the block and the state BEFORE
@@ -544,11 +582,19 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
 #else
 #define CK(k) do { } while (0)
 #endif
+    // the head of correction pv, in registers; != 0: its S was singular (read in one LDS round trip, in front of the branch on it)
+    double hP[18];
+    auto load_head = [&]() {
+        const int sg = hi[hb];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) hP[q] = hd[hb][q];
+        return sg;
+    };
+    int4 dn = dlive[0];                   // the next live correction: { marker, first state index, resolved id, init }
     // one phase: what correction pv leaves (if `have`), and the head of correction st (if has_cur)
-    auto phase = [&](const bool has_cur, const int st, const bool cur_init) {
+    auto phase = [&](const bool has_cur, const int st, const bool cur_init, const int k_next) {
         const double (*B0)[NU + 1] = BK[bcur];                          // the block before correction pv, complete
         const double* S0 = SM[scur];
-        const double* hP = hd[hb];
         double* hN = hd[hb ^ 1];
         const int posP = pv_pos, cP = pv_c;
         const int spP[5] = { 0, 1, 2, posP, posP + 1 };                 // positions of set_pv in U
@@ -641,7 +687,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                         else if (w == 1) word = (long long)(unsigned)cP | ((long long)pv_id << 32);
                         else {
                             const int f = w - 2;                        // 0..13: Hc, Sinv = hd[0..13]; 14, 15: dz = hd[16], hd[17]; 16, 17: lxy = hd[14], hd[15]
-                            word = __double_as_longlong(hP[f < 14 ? f : (f < 16 ? f + 2 : f - 2)]);
+                            word = __double_as_longlong(hd[hb][f < 14 ? f : (f < 16 ? f + 2 : f - 2)]);
                         }
                         st_agent(reinterpret_cast<long long*>(psP) + w, word);
                     }
@@ -691,24 +737,70 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                         } else ent = pij;
                     }
                     CK(4);
-                    double Hc[10], S[4], Si[4], pb[5][5];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q)
-#pragma unroll
-                        for (int q2 = 0; q2 < 5; ++q2) pb[q][q2] = lane_bcast(ent, 5 * q + q2);   // pb[q][q2] = P(set[q2], set[q])
-                    jacobian_compact(x, y, lx, ly, Hc);                 // :268
+                    // H (:268), S = H P H^T + R and S^-1 (:270) with the lanes of this wave side by side: a wave issues one fp64
+                    // instruction per ~6.6 cycles whether 1 or 64 lanes take part (tools/microbench/latency.hip), so the four
+                    // quotients of the Jacobian are ONE division on four lanes, the ten entries of H P one 5-FMA chain on ten
+                    // lanes, S one on four, S^-1 one division on four.  Every value is formed by the operations of
+                    // jacobian_compact / innovation_cov_block / inv2 in their order.
+                    const double dx = lx - x, dy = ly - y;
+                    const double dd = (dx * dx) + (dy * dy);
+                    const double sd = sqrt(dd);
+                    const int k4 = lane & 3;
+                    const double qv = ((k4 & 1) ? dy : dx) / ((k4 & 2) ? dd : sd);        // lanes 0..3: dx/sd, dy/sd, dx/d, dy/d
+                    const double xs = lane_bcast(qv, 0), ys = lane_bcast(qv, 1), xd = lane_bcast(qv, 2), yd = lane_bcast(qv, 3);
+                    // Hc[r + 2 q] = H(r, set[q]) = { 0, -1 | -xs, yd | -ys, -xd | xs, -yd | ys, xd }: named scalars, selected per lane
+                    // (an array indexed by a lane-dependent row would live in scratch memory)
+                    const double nxs = -xs, nys = -ys, nxd = -xd, nyd = -yd;
+#define NUSLAM_HROW(rr, k) ((k) == 0 ? ((rr) ? -1.0 : 0.0) : (k) == 1 ? ((rr) ? yd : nxs) : (k) == 2 ? ((rr) ? nxd : nys) \
+                            : (k) == 3 ? ((rr) ? nyd : xs) : ((rr) ? xd : ys))
                     CK(5);
-                    innovation_cov_block(pb, Hc, v.R, S);               // H P H^T + R, :270
+                    // (H P)(r, set[q]) on lane 2 q + r: the sum over q2 of H(r, set[q2]) P(set[q2], set[q]), ascending
+                    double hp = 0.0;
+                    {
+                        const int L = lane < 10 ? lane : 0, q = L >> 1, r = L & 1;
+#pragma unroll
+                        for (int q2 = 0; q2 < 5; ++q2) {
+                            const double pv = __shfl(ent, 5 * q + q2, 64);
+                            hp = fma(NUSLAM_HROW(r, q2), pv, hp);
+                        }
+                    }
+                    // S(r, s2) on lane r + 2 s2: the sum over q of (H P)(r, set[q]) H(s2, set[q]), ascending, then + R
+                    double Sv;
+                    {
+                        const int M = lane & 3, r = M & 1, s2 = M >> 1;
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            const double hv = __shfl(hp, 2 * q + r, 64);
+                            sacc = fma(hv, NUSLAM_HROW(s2, q), sacc);
+                        }
+                        const double R0 = v.R[0], R1 = v.R[1], R2 = v.R[2], R3 = v.R[3];
+                        Sv = sacc + (M == 0 ? R0 : M == 1 ? R1 : M == 2 ? R2 : R3);
+                    }
                     CK(6);
-                    const int sing = inv2(S, Si);
+                    // S^-1 (inv2: Armadillo's tiny-matrix inverse; general LU when |det| < epsilon), column-major: entry M on lane M
+                    const double sa = lane_bcast(Sv, 0), sc = lane_bcast(Sv, 1), sb = lane_bcast(Sv, 2), sdd = lane_bcast(Sv, 3);
+                    const double det = (sa * sdd) - (sb * sc);
+                    double Siv;
+                    int sing = 0;
+                    if (fabs(det) >= DBL_EPSILON) {
+                        const int M = lane & 3;
+                        Siv = (M == 0 ? sdd : M == 1 ? -sc : M == 2 ? -sb : sa) / det;
+                    } else {
+                        const double S4[4] = { sa, sc, sb, sdd };
+                        double Si[4];
+                        sing = inv2(S4, Si);
+                        const int M = lane & 3;
+                        Siv = M == 0 ? Si[0] : M == 1 ? Si[1] : M == 2 ? Si[2] : Si[3];
+                    }
+                    if (lane < 4) hN[10 + lane] = Siv;
                     if (lane == 0) {
-#pragma unroll
-                        for (int q = 0; q < 10; ++q) hN[q] = Hc[q];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) hN[10 + q] = Si[q];
+                        hN[0] = 0.0; hN[1] = -1.0; hN[2] = nxs; hN[3] = yd; hN[4] = nys; hN[5] = nxd; hN[6] = xs; hN[7] = nyd;
+                        hN[8] = ys; hN[9] = xd;
                         hN[14] = lx; hN[15] = ly;
                         hi[hb ^ 1] = sing;
                     }
+#undef NUSLAM_HROW
                 } else {
                     const double mx = lx - x, my = ly - y;              // measurement(): :152-156
                     double zr_h, zb_h;
@@ -723,51 +815,53 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         }
         // (PUBLISH: the stores of entry pv -- wave 0's rows of M and heading, wave 1's prior rows and scalars, issued at the top
         // of this phase -- are waited for here)
-        if (PUBLISH && (wave == 0 || wave == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (PUBLISH && wave != 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (wave 2: the entries of the skipped markers)
+        dn = dlive[k_next];                                             // (for the next trip; it arrives while this wave waits below)
         CK(0);
         lds_barrier();
         CK(1);
         if (have) { scur ^= 1; bcur ^= 1; }
         hb ^= 1;
     };
+    int sing_at = 255;                    // first marker whose S was singular
+    // the singular S of correction pv (update() throws behind initializeLandmark, slam_library.cpp:263-270): nothing but the first
+    // sighting's state rows changes
+    auto settle_singular = [&]() {
+        TickStep* psP = pl + pv_st;
+        const double lx = hP[14], ly = hP[15];
+        const int fresh = BK[bcur][pv_pos][pv_pos] > 1.0e9 ? 2 : 0;
+        if (sing_at == 255) sing_at = pv_st;
+        if (tid == 0) {
+            plan_store_head(PUBLISH, psP, 1, (pv_init ? 1 : 0) | fresh, pv_c, pv_id);
+            plan_store(PUBLISH, &psP->lxy[0], lx); plan_store(PUBLISH, &psP->lxy[1], ly);
+        }
+        if (pv_init && tid < NU) {
+            const int i = Ush[tid];
+            if (i == pv_c) SM[scur][tid] = lx;
+            if (i == pv_c + 1) SM[scur][tid] = ly;
+        }
+        lds_barrier();
+        have = false;
+    };
 #ifdef NUSLAM_CHAIN_CLOCK
     const long long sclk0 = (long long)clock64(), wclk0 = (long long)wall_clock64();
 #endif
-    for (int st = 0; st < J; ++st) {
+    TL(1, PUBLISH && b == 0 && tid == 0);                               // chain: loop start
+    for (int k = 0; k < nlive; ++k) {
         CK(7);
-        const Decision d = resolve(v.n, idsh[st], seen, cached, brk, status, MODE_KNOWN, total_landmarks);   // slam.cpp:295-316
-        seen = d.new_seen; brk = d.new_brk; status = d.new_status;
-        TickStep* ps = pl + st;
-        if (tid == 0 && v.id_log && o.log_slot0 >= 0) v.id_log[(size_t)b * v.log_stride + o.log_slot0 + st] = d.id;
-        if (d.skip) {
-            if (tid == 0) plan_store_head(PUBLISH, ps, 1, 0, 3, d.id);
-            continue;
-        }
-        const int pos = 3 + 2 * st, c = d.c;
-        phase(true, st, d.init);
-        // entries 0 .. st-1 are complete: waves 0 and 1 waited for their stores in front of the barrier just passed
+        const int4 dc = dn;
+        const int st = dc.x;
+        if (have && load_head() != 0) settle_singular();
+        phase(true, st, dc.w != 0, k + 1);
+        // entries 0 .. st-1 are complete: the storing waves waited for their stores in front of the barrier just passed
         if (PUBLISH && tid == 192) st_agent(pub.flag + kPubWords * b, (int)((unsigned)pub.base + (unsigned)st));
-        if (hi[hb] != 0) {                                              // singular S: update() throws after the init
-            const double lx = hd[hb][14], ly = hd[hb][15];
-            const int fresh = BK[bcur][pos][pos] > 1.0e9 ? 2 : 0;
-            if (status == 0) status = kStatusSingular;
-            if (tid == 0) {
-                plan_store_head(PUBLISH, ps, 1, (d.init ? 1 : 0) | fresh, c, d.id);
-                plan_store(PUBLISH, &ps->lxy[0], lx); plan_store(PUBLISH, &ps->lxy[1], ly);
-            }
-            if (d.init && tid < NU) {
-                const int i = Ush[tid];
-                if (i == c) SM[scur][tid] = lx;
-                if (i == c + 1) SM[scur][tid] = ly;
-            }
-            lds_barrier();
-            have = false;
-            continue;
-        }
         have = true;
-        pv_st = st; pv_pos = pos; pv_c = c; pv_id = d.id; pv_init = d.init;
+        pv_st = st; pv_pos = 3 + 2 * st; pv_c = dc.y; pv_id = dc.z; pv_init = dc.w != 0;
     }
-    if (have) phase(false, 0, false);                                   // what the last correction leaves: its plan entry
+    if (have && load_head() != 0) settle_singular();
+    if (status == 0) status = dsum[2] < sing_at ? kStatusBounds : (sing_at != 255 ? kStatusSingular : 0);
+    TL(2, PUBLISH && b == 0 && tid == 0);                               // chain: loop end
+    if (have) phase(false, 0, false, 0);                                   // what the last correction leaves: its plan entry
 #ifdef NUSLAM_CHAIN_CLOCK
     if (wave == 3) {                                                    // shader cycles per 100 MHz tick over the loop: the clock the CU ran at
         ck[2] = (long long)clock64() - sclk0;
@@ -790,6 +884,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         __syncthreads();
         if (tid == 0) tick_signal(done_cnt);
     }
+    TL(3, PUBLISH && b == 0 && tid == 0);                               // chain: exit
 }
 
 template <typename T, bool FUSED>
@@ -1096,9 +1191,10 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     const int J = o.J;
     double* Kb = Kbuf + (size_t)b * kTickJ * 2 * ld;
     double* Rb = Rbuf + (size_t)b * kTickJ * 5 * ld;
-    __shared__ long long slot[kPlanWords];                              // the plan entry in flight
-    __shared__ int ok_sh;
-    const TickStep* ps = reinterpret_cast<const TickStep*>(slot);
+    __shared__ long long slot[2][kPlanWords];                           // the plan entry being applied / the next one
+    __shared__ int ok_sh, fail_sh;
+    if (threadIdx.x == 0) fail_sh = 0;
+    __syncthreads();
 
     int Uk[kQuadRows];
 #pragma unroll
@@ -1151,27 +1247,59 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         if (role == 1) sv = v.s_in[(size_t)b * ld + tr];
     }
     const long long* src = reinterpret_cast<const long long*>(plan + (size_t)b * kTickJ);
+    // Entry st+1 is FETCHED WHILE entry st is applied whenever the chain has already announced it (a workgroup that has fallen
+    // behind the chain catches up at the pace of its arithmetic, ~0.6 us per entry, instead of flag + fetch + arithmetic in a
+    // row): each wave looks at the flag itself and fetches its own words of the entry -- every load of handed-off bytes an
+    // agent-scope load, issued behind the flag's --, one barrier per entry makes the slot whole.  Waits are bounded as before.
+    const int* const flagp = pub.flag + kPubWords * b;
+    constexpr int kW = (kPlanWords + 255) / 256;
+    auto published = [&](int st) {
+        const int f = __builtin_amdgcn_readfirstlane(ld_agent(flagp));
+        return seq_reached(f, (int)((unsigned)pub.base + (unsigned)(st + 1)));
+    };
+    auto wait_entry = [&](int st) {
+        for (int it = 0; it < (1 << 18); ++it) {
+            if (published(st)) return true;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        return false;
+    };
+    long long rw[kW];
+    auto fetch = [&](int st) {
+        const long long* e = src + (size_t)st * kPlanWords;
+#pragma unroll
+        for (int u = 0; u < kW; ++u) {
+            const int w = (int)threadIdx.x + 256 * u;
+            rw[u] = ld_agent(e + (w < kPlanWords ? w : 0));
+        }
+    };
+    auto stash = [&](int st) {
+#pragma unroll
+        for (int u = 0; u < kW; ++u) {
+            const int w = (int)threadIdx.x + 256 * u;
+            if (w < kPlanWords) slot[st & 1][w] = rw[u];
+        }
+    };
+    if (!failed && J > 0) {
+        if (wait_entry(0)) { fetch(0); stash(0); }
+        else if ((threadIdx.x & 63) == 0) fail_sh = 1;
+    }
+    __syncthreads();
+    if (!failed && fail_sh != 0) {
+        failed = true;
+        if (threadIdx.x == 0) atomicAdd(timeouts, 1);
+    }
 
 #pragma unroll
     for (int st = 0; st < kTickJ; ++st) {
         if (st < J && !failed) {                                        // (uniform)
-            // ---- wait for entry st, fetch it (every load of the handed-off bytes is an agent-scope load)
-            if (threadIdx.x == 0) {
-                int ok = 0;
-                for (int it = 0; it < (1 << 18); ++it) {
-                    if (seq_reached(ld_agent(pub.flag + kPubWords * b), (int)((unsigned)pub.base + (unsigned)(st + 1)))) { ok = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                ok_sh = ok;
+            const TickStep* ps = reinterpret_cast<const TickStep*>(slot[st & 1]);
+            bool pre = false;
+            if (st + 1 < J) {
+                pre = published(st + 1);
+                if (pre) fetch(st + 1);
             }
-            __syncthreads();
-            if (!ok_sh) {
-                failed = true;
-                if (threadIdx.x == 0) atomicAdd(timeouts, 1);
-            } else {
-                const long long* e = src + (size_t)st * kPlanWords;
-                for (int w = threadIdx.x; w < kPlanWords; w += 256) slot[w] = ld_agent(e + w);
-                __syncthreads();
+            {
                 const bool act = ps->skip == 0;
                 const bool init = (ps->init & 1) != 0;
                 const int c = ps->c;
@@ -1239,6 +1367,18 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             PN[j] = on ? nv : PN[j];
                         }
                     }
+                }
+            }
+            if (st + 1 < J) {
+                if (!pre) {
+                    if (wait_entry(st + 1)) { fetch(st + 1); pre = true; }
+                    else if ((threadIdx.x & 63) == 0) fail_sh = 1;
+                }
+                if (pre) stash(st + 1);
+                __syncthreads();
+                if (fail_sh != 0) {
+                    failed = true;
+                    if (threadIdx.x == 0) atomicAdd(timeouts, 1);
                 }
             }
         }
@@ -1334,8 +1474,19 @@ __global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total
     const int b = blockIdx.y;
     const int x = blockIdx.x;
     if (x == 0) tick_chain<T, false, true>(b, v, o, total_landmarks, P, plan, TickCarry{}, nullptr, nullptr, pub);
-    else if (x <= n_pred) tick_predict_role<T>(b, x - 1, v, pub, P, timeouts);
-    else tick_panels_stream<T>(b, x - 1 - n_pred, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
+    else if (x <= n_pred) {
+        TL(4, b == 0 && x == 1 && threadIdx.x == 0);                    // predict role: entry / exit
+        tick_predict_role<T>(b, x - 1, v, pub, P, timeouts);
+        TL(5, b == 0 && x == 1 && threadIdx.x == 0);
+    } else {
+        const int last = (int)gridDim.x - 1, mid = (n_pred + 1 + last) / 2;
+        (void)last; (void)mid;
+        TL(6, b == 0 && x == mid && threadIdx.x == 0);                  // strips: a middle workgroup and the last one, entry / exit
+        TL(8, b == 0 && x == last && threadIdx.x == 0);
+        tick_panels_stream<T>(b, x - 1 - n_pred, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
+        TL(7, b == 0 && x == mid && threadIdx.x == 0);
+        TL(9, b == 0 && x == last && threadIdx.x == 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ the pass over P

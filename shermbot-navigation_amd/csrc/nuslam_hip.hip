@@ -1732,6 +1732,12 @@ extern "C" int nuslam_debug_panels_clock(long long out[40])
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_panels_clock), sizeof(long long) * 40));
     return NUSLAM_OK;
 }
+extern "C" int nuslam_debug_front_timeline(long long out[16])
+{
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_front_tl), sizeof(long long) * 16));
+    return NUSLAM_OK;
+}
 extern "C" int nuslam_debug_chain_clock(long long out[32])
 {
     HIPCHK(hipDeviceSynchronize());

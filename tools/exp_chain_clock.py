@@ -18,9 +18,12 @@ bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
 bt.run(0, 30); bt.sync()
 L = nh.lib(); L.nuslam_debug_chain_clock.argtypes = [C.POINTER(C.c_longlong)]
 acc = []
+tls = []
+L.nuslam_debug_front_timeline.argtypes = [C.POINTER(C.c_longlong)]
 for t in range(30, 40):
     bt.run(t, t + 1); bt.sync()
     out = (C.c_longlong * 32)(); L.nuslam_debug_chain_clock(out); acc.append(list(out))
+    tl = (C.c_longlong * 16)(); L.nuslam_debug_front_timeline(tl); tls.append(list(tl))
 raw = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8)
 print("shader clock over the loop: %.0f MHz (%d cycles in %.2f us)" % (100.0 * raw[3, 2] / raw[3, 3], raw[3, 2], raw[3, 3] * 0.01))
 raw[3, 2] = raw[3, 3] = 0
@@ -30,3 +33,11 @@ a = raw * 0.01 / m   # us per step
 names = ["rest", "barrier", "stores", "rows", "entries|polar", "bcast+H", "S", "loop top"]
 for w in range(4):
     print("wave %d: " % w + ", ".join("%s %.2f" % (names[k], a[w, k]) for k in (7, 2, 3, 4, 5, 6, 0, 1)) + "  | sum %.2f us/step" % a[w].sum())
+
+if not os.environ.get("CHAIN_ONLY"):
+    # the launch's timeline, us from the chain's entry (median over the ticks)
+    t = np.array(tls, dtype=np.float64)
+    t = (t - t[:, :1]) * 0.01
+    med = np.median(t, axis=0)
+    print("k_tick_front timeline (us after the chain workgroup's entry): chain loop start %.2f, loop end %.2f, exit %.2f | predict workgroup %.2f .. %.2f"
+          " | strips: middle workgroup %.2f .. %.2f, last workgroup %.2f .. %.2f" % tuple(med[1:10]))
