@@ -103,6 +103,44 @@ __device__ inline double normalize_angle(double rad)
     return r;
 }
 
+// predictEstimate (slam_library.cpp:71-94) and getA's two entries (:127-148, at the heading AFTER predictEstimate) for one filter;
+// every lane of a full wave calls it with the same arguments.  The reference's eight sines and cosines are TWO library calls
+// with four lanes side by side (theta, theta + dth, th1, th1 + dth) instead of eight in a row -- a wave issues ~one fp64
+// instruction per 6.6 cycles however many lanes take part, and the eight calls were 2.4 us at the head of every tick.  Each value is
+// the library's for that argument; the expressions around them are the reference's, term for term.
+struct MotionStep { double dq_th, dq_x, dq_y, th1, a1, a2; };
+__device__ inline double wave_bcast(double val, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(val), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(val), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline MotionStep motion_step(double theta, double dth, double dx)
+{
+    MotionStep m;
+    m.dq_th = dth == 0.0 ? 0.0 : dth;
+    m.th1 = theta + m.dq_th;
+    const int k = threadIdx.x & 3;
+    const double ang = k == 0 ? theta : k == 1 ? theta + dth : k == 2 ? m.th1 : m.th1 + dth;
+    const double sv = sin(ang), cv = cos(ang);
+    const double s_th = wave_bcast(sv, 0), c_th = wave_bcast(cv, 0);          // sin / cos of theta
+    const double s_th_d = wave_bcast(sv, 1), c_th_d = wave_bcast(cv, 1);      // ... of theta + dth
+    const double s_t1 = wave_bcast(sv, 2), c_t1 = wave_bcast(cv, 2);          // ... of th1
+    const double s_t1_d = wave_bcast(sv, 3), c_t1_d = wave_bcast(cv, 3);      // ... of th1 + dth
+    if (dth == 0.0) {
+        m.dq_x = dx * c_th;
+        m.dq_y = dx * s_th;
+        m.a1 = -dx * s_t1;
+        m.a2 = dx * c_t1;
+    } else {
+        m.dq_x = -(dx / dth) * s_th + (dx / dth) * s_th_d;
+        m.dq_y = (dx / dth) * c_th - (dx / dth) * c_th_d;
+        m.a1 = -(dx / dth) * c_t1 + (dx / dth) * c_t1_d;
+        m.a2 = -(dx / dth) * s_t1 + (dx / dth) * s_t1_d;
+    }
+    return m;
+}
+
 __device__ inline void cartesian2polar(double x, double y, double& r, double& b) // slam_library.cpp:16-22
 {
     r = sqrt((x * x) + (y * y));

@@ -108,26 +108,8 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
 
     // predictEstimate, slam_library.cpp:71-94
     const double theta = s[0];
-    double dq_th, dq_x, dq_y;
-    if (dth == 0.0) {
-        dq_th = 0.0;
-        dq_x = dx * cos(theta);
-        dq_y = dx * sin(theta);
-    } else {
-        dq_th = dth;
-        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
-        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
-    }
-    const double th1 = theta + dq_th;
-    // getA, slam_library.cpp:127-148 -- evaluated at the heading AFTER predictEstimate (:66-67,129)
-    double a1, a2;
-    if (dth == 0) {
-        a1 = -dx * sin(th1);
-        a2 = dx * cos(th1);
-    } else {
-        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
-        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
-    }
+    const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
+    const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
     if (t < v.ld) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
 
     if (STATE_ONLY) {

@@ -212,25 +212,8 @@ __device__ inline void predict_block(const View& v, const TwistArg& tw, int b, c
     const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
     const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
     const double theta = SF[0];
-    double dq_th, dq_x, dq_y;
-    if (dth == 0.0) {
-        dq_th = 0.0;
-        dq_x = dx * cos(theta);
-        dq_y = dx * sin(theta);
-    } else {
-        dq_th = dth;
-        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
-        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
-    }
-    const double th1 = theta + dq_th;
-    double a1, a2;
-    if (dth == 0) {
-        a1 = -dx * sin(th1);
-        a2 = dx * cos(th1);
-    } else {
-        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
-        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
-    }
+    const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
+    const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
     if (tid < NU) {
         const int p = tid;
         SMo[p] = p == 0 ? th1 : p == 1 ? SF[1] + dq_x : p == 2 ? SF[2] + dq_y : SF[p];
@@ -484,11 +467,14 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             // place): what was just gathered is the covariance BEFORE it.  Let them go, and apply predict to the block and
             // the pose here, with k_predict's own arithmetic (predict_block); the tick's bookkeeping (slam.cpp:250-251) too.
             __syncthreads();                                            // (every gathered value has arrived)
+            TL(10, b == 0 && tid == 0);                                 // chain: block gathered
             if (tid == 0) st_agent(pub.flag + kPubWords * b + 1, pub.gbase);
             for (int e = tid; e < NU * (NU + 1); e += 256) (&BK[1][0][0])[e] = (&BK[0][0][0])[e];
             if (tid < NU) SM[1][tid] = SM[0][tid];
             __syncthreads();
+            TL(11, b == 0 && tid == 0);
             predict_block<T>(v, pub.tw, b, BK[1], BK[0], SM[1], SM[0]);
+            TL(12, b == 0 && tid == 0);                                 // chain: predict applied to the block
             cached = seen; brk = 0;
         }
     }
@@ -1410,25 +1396,8 @@ __device__ inline void tick_predict_role(const int b, const int blk, View v, Tic
     const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
     const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
     const double theta = s[0];
-    double dq_th, dq_x, dq_y;
-    if (dth == 0.0) {
-        dq_th = 0.0;
-        dq_x = dx * cos(theta);
-        dq_y = dx * sin(theta);
-    } else {
-        dq_th = dth;
-        dq_x = -(dx / dth) * sin(theta) + (dx / dth) * sin(theta + dth);
-        dq_y = (dx / dth) * cos(theta) - (dx / dth) * cos(theta + dth);
-    }
-    const double th1 = theta + dq_th;
-    double a1, a2;
-    if (dth == 0) {
-        a1 = -dx * sin(th1);
-        a2 = dx * cos(th1);
-    } else {
-        a1 = -(dx / dth) * cos(th1) + (dx / dth) * cos(th1 + dth);
-        a2 = -(dx / dth) * sin(th1) + (dx / dth) * sin(th1 + dth);
-    }
+    const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
+    const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
     if (t < ld) st_agent(&so[t], t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t]);
     T* Pb = P + (size_t)b * v.p_stride;
     if (t == 0) {
