@@ -204,15 +204,13 @@ __global__ __launch_bounds__(64) void k_tick_signal(int* __restrict__ cnt)
 // full covariance (slam_library.cpp:65-148: pose advance, A = I + B at the advanced heading, A P A^T + Qbar restricted to the
 // block; positions 0, 1, 2 of U are the pose).  FBs / SF: block and state before, BKo / SMo: after.  256 threads.
 template <typename T>
-__device__ inline void predict_block(const View& v, const TwistArg& tw, int b, const double (*FBs)[kTickNU + 1],
+__device__ inline void predict_block(const View& v, const MotionStep& ms, const double (*FBs)[kTickNU + 1],
                                      double (*BKo)[kTickNU + 1], const double* SF, double* SMo)
 {
+    // ms: motion_step(SF[0], this tick's twist) -- predictEstimate :71-94, getA :127-148 (formed by the caller, who can do it
+    // while the block is still on its way)
     constexpr int NU = kTickNU, NT = 256;
     const int tid = threadIdx.x;
-    const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
-    const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
-    const double theta = SF[0];
-    const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
     const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
     if (tid < NU) {
         const int p = tid;
@@ -371,7 +369,12 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
     __syncthreads();
 
     // ---- this tick's predict on the block and the pose, as k_predict does it (slam_library.cpp:65-148)
-    predict_block<T>(v, cy.tw, b, FBs, BKo, SF, SMo);
+    {
+        const TwistArg& tw = cy.tw;
+        const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
+        const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
+        predict_block<T>(v, motion_step(SF[0], dth, dx), FBs, BKo, SF, SMo);
+    }
     const int* c4 = ctrl4 + 4 * b;
     seen = c4[0]; cached = c4[0]; brk = 0; status = c4[3];              // slam.cpp:250-251 at this tick's top
     __syncthreads();
@@ -453,32 +456,65 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         if (!tick_wait(cy.wait_cnt, cy.wait_target) && tid == 0) atomicAdd(cy.timeouts, 1);
         tick_carry<T>(v, b, cy, Ush, BK[1], BK[0], SM[0], ctrl_out4, seen, cached, brk, status);
     } else {
-        for (int e = tid; e < NU * NU; e += 256) {
-            // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
-            // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
-            const int q = e / NU, p = e % NU;
-            BK[0][p][q] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+        // Everything the round starts from is REQUESTED first -- this tick's twist and heading, the markers, the control words, the
+        // 35 x 35 block -- and what does not need the block is computed while it is on its way: the motion step's sines and
+        // cosines (motion_step), the markers' polar forms.
+        const bool fpred = PUBLISH && pub.predict;                      // the tick's predict runs in THIS launch (k_tick_front)
+        double (*G)[NU + 1] = fpred ? BK[1] : BK[0];
+        double* GS = fpred ? SM[1] : SM[0];
+        double dth = 0.0, dxx = 0.0, theta = 0.0;
+        if (fpred) {
+            const TwistArg& tw = pub.tw;
+            dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
+            dxx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
+            theta = s[0];
         }
-        if (tid < NU) SM[0][tid] = s[Ush[tid]];
+        double oa = 0.0, ob = 0.0;
+        if (wave == 3 && lane < J) {
+            oa = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
+            ob = o.b ? o.b[b * o.stride + o.off + lane] : o.b0[lane];
+        }
         const int* ci = v.c_in + b * C_WORDS;
         seen = ci[C_SEEN]; brk = ci[C_BRK]; status = ci[C_STATUS]; cached = ci[C_SEEN_CACHED];
-        if (PUBLISH && pub.predict) {
-            // The tick's predict runs in THIS launch (the middle workgroups of k_tick_front rewrite rows / columns 1, 2 of P in
-            // place): what was just gathered is the covariance BEFORE it.  Let them go, and apply predict to the block and
-            // the pose here, with k_predict's own arithmetic (predict_block); the tick's bookkeeping (slam.cpp:250-251) too.
+        constexpr int NG = (NU * NU + 255) / 256;
+        double g[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
+            // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
+            const int e = tid + 256 * u, ec = e < NU * NU ? e : 0;
+            const int q = ec / NU, p = ec % NU;
+            g[u] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+        }
+        const double gs = s[Ush[tid < NU ? tid : 0]];
+        MotionStep ms{};
+        if (fpred) ms = motion_step(theta, dth, dxx);
+        if (wave == 3 && lane < kTickJ) {         // all markers' polar forms at once, one lane each
+            double r, phi;
+            if (o.cartesian) cartesian2polar(oa, ob, r, phi);
+            else { r = oa; phi = ob; }
+            zr[lane] = r;
+            zphi[lane] = phi;
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int e = tid + 256 * u;
+            if (e < NU * NU) G[e % NU][e / NU] = g[u];
+        }
+        if (tid < NU) GS[tid] = gs;
+        if (fpred) {
+            // What was just gathered is the covariance BEFORE predict (the middle workgroups of k_tick_front rewrite rows / columns
+            // 1, 2 of P in place): let them go, and apply predict to the block and the pose here, with k_predict's own
+            // arithmetic (predict_block); the tick's bookkeeping (slam.cpp:250-251) too.
             __syncthreads();                                            // (every gathered value has arrived)
             TL(10, b == 0 && tid == 0);                                 // chain: block gathered
             if (tid == 0) st_agent(pub.flag + kPubWords * b + 1, pub.gbase);
-            for (int e = tid; e < NU * (NU + 1); e += 256) (&BK[1][0][0])[e] = (&BK[0][0][0])[e];
-            if (tid < NU) SM[1][tid] = SM[0][tid];
-            __syncthreads();
-            TL(11, b == 0 && tid == 0);
-            predict_block<T>(v, pub.tw, b, BK[1], BK[0], SM[1], SM[0]);
+            predict_block<T>(v, ms, BK[1], BK[0], SM[1], SM[0]);
             TL(12, b == 0 && tid == 0);                                 // chain: predict applied to the block
             cached = seen; brk = 0;
         }
     }
-    if (wave == 3 && lane < kTickJ) {             // all markers' polar forms at once, one lane each
+    if (FUSED && wave == 3 && lane < kTickJ) {    // (overlapped runs: the markers' polar forms)
         double a = 0.0, bb = 0.0;
         if (lane < J) {
             a = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
