@@ -460,8 +460,6 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         // 35 x 35 block -- and what does not need the block is computed while it is on its way: the motion step's sines and
         // cosines (motion_step), the markers' polar forms.
         const bool fpred = PUBLISH && pub.predict;                      // the tick's predict runs in THIS launch (k_tick_front)
-        double (*G)[NU + 1] = fpred ? BK[1] : BK[0];
-        double* GS = fpred ? SM[1] : SM[0];
         double dth = 0.0, dxx = 0.0, theta = 0.0;
         if (fpred) {
             const TwistArg& tw = pub.tw;
@@ -477,7 +475,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         const int* ci = v.c_in + b * C_WORDS;
         seen = ci[C_SEEN]; brk = ci[C_BRK]; status = ci[C_STATUS]; cached = ci[C_SEEN_CACHED];
         constexpr int NG = (NU * NU + 255) / 256;
-        double g[NG];
+        double g[NG], gp[NG];
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             // consecutive lanes walk DOWN a column: the two rows of a landmark share a cache line (each scattered 8-byte
@@ -485,7 +483,16 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             const int e = tid + 256 * u, ec = e < NU * NU ? e : 0;
             const int q = ec / NU, p = ec % NU;
             g[u] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+            // fpred: the entry of row 0 (column 0) predict combines it with (predict_block's column / row role), fetched by the
+            // thread itself so that predict can be applied before anything passes through LDS
+            gp[u] = 0.0;
+            {
+                const bool colr = q >= 3 && (p == 1 || p == 2), rowr = p >= 3 && (q == 1 || q == 2);
+                if (fpred && (colr || rowr)) gp[u] = (double)Pb[(size_t)(rowr ? 0 : Ush[q]) * ld + (colr ? 0 : Ush[p])];   // (128 of the 1225)
+            }
         }
+        double gc = 0.0;                                                // the 3 x 3 pose corner, entry (i, j) on lane i + 3 j of wave 0
+        if (fpred && tid < 9) gc = (double)Pb[(size_t)(tid / 3) * ld + tid % 3];
         const double gs = s[Ush[tid < NU ? tid : 0]];
         MotionStep ms{};
         if (fpred) ms = motion_step(theta, dth, dxx);
@@ -496,22 +503,58 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             zr[lane] = r;
             zphi[lane] = phi;
         }
+        // What was gathered is the covariance BEFORE predict (the middle workgroups of k_tick_front rewrite rows / columns 1, 2 of P
+        // in place once told that it has arrived): predict is applied to the block and the pose on the way into LDS, with
+        // k_predict's own arithmetic entry by entry (the cases of predict_block; slam_library.cpp:65-148)
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             const int e = tid + 256 * u;
-            if (e < NU * NU) G[e % NU][e / NU] = g[u];
+            if (e < NU * NU) {
+                const int q = e / NU, p = e % NU;
+                double val = g[u];
+                if (fpred) {
+                    if (q >= 3 && (p == 1 || p == 2)) val = (double)(T)((p == 1 ? ms.a1 : ms.a2) * gp[u] + val);
+                    else if (p >= 3 && (q == 1 || q == 2)) val = (double)(T)(gp[u] * (q == 1 ? ms.a1 : ms.a2) + val);
+                }
+                if (!(fpred && p < 3 && q < 3)) BK[0][p][q] = val;      // (the corner: thread 0 below)
+            }
         }
-        if (tid < NU) GS[tid] = gs;
+        if (fpred && wave == 0) {
+            double pp[3][3], tt[3][3], uu[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) pp[i][j] = lane_bcast(gc, i + 3 * j);
+            const double a1 = ms.a1, a2 = ms.a2;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                tt[0][j] = pp[0][j];
+                tt[1][j] = a1 * pp[0][j] + pp[1][j];
+                tt[2][j] = a2 * pp[0][j] + pp[2][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                uu[i][0] = tt[i][0];
+                uu[i][1] = tt[i][0] * a1 + tt[i][1];
+                uu[i][2] = tt[i][0] * a2 + tt[i][2];
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) BK[0][i][j] = (double)(T)(uu[i][j] + v.Q[i + 3 * j]);
+            }
+        }
+        if (tid < NU) {
+            double sv = gs;
+            if (fpred) sv = tid == 0 ? ms.th1 : tid == 1 ? gs + ms.dq_x : tid == 2 ? gs + ms.dq_y : gs;
+            SM[0][tid] = sv;
+        }
         if (fpred) {
-            // What was just gathered is the covariance BEFORE predict (the middle workgroups of k_tick_front rewrite rows / columns
-            // 1, 2 of P in place): let them go, and apply predict to the block and the pose here, with k_predict's own
-            // arithmetic (predict_block); the tick's bookkeeping (slam.cpp:250-251) too.
-            __syncthreads();                                            // (every gathered value has arrived)
-            TL(10, b == 0 && tid == 0);                                 // chain: block gathered
+            __syncthreads();                                            // (every gathered value has arrived: the predict workgroups may go)
+            TL(10, b == 0 && tid == 0);                                 // chain: block gathered, predict applied
             if (tid == 0) st_agent(pub.flag + kPubWords * b + 1, pub.gbase);
-            predict_block<T>(v, ms, BK[1], BK[0], SM[1], SM[0]);
-            TL(12, b == 0 && tid == 0);                                 // chain: predict applied to the block
-            cached = seen; brk = 0;
+            cached = seen; brk = 0;                                     // the tick's bookkeeping (slam.cpp:250-251)
         }
     }
     if (FUSED && wave == 3 && lane < kTickJ) {    // (overlapped runs: the markers' polar forms)

@@ -41,4 +41,4 @@ if not os.environ.get("CHAIN_ONLY"):
     med = np.median(t, axis=0)
     print("k_tick_front timeline (us after the chain workgroup's entry): chain loop start %.2f, loop end %.2f, exit %.2f | predict workgroup %.2f .. %.2f"
           " | strips: middle workgroup %.2f .. %.2f, last workgroup %.2f .. %.2f" % tuple(med[1:10]))
-    print("   chain prologue: block gathered %.2f, predict applied %.2f" % (med[10], med[12]))
+    print("   chain prologue: block gathered and predict applied %.2f" % med[10])
