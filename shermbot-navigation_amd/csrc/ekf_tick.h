@@ -81,7 +81,8 @@ struct alignas(16) TickStep {
 // What an overlapped run's chain starts from instead of the covariance (FUSED): the strips of the PREVIOUS tick at this
 // tick's index set, dropped into compact arrays by k_tick_panels, the 35 x 35 block k_tick_prep gathered from the
 // covariance the previous pass reads, that tick's plan and control words, this tick's twist.
-constexpr int kTickCarryLds = ((kTickJ - 7) * 5 * (kTickNU + 1) + kTickJ * 12 + kTickNU + 1) * (int)sizeof(double);
+// dynamic LDS of a FUSED chain (tick_carry): the previous tick's R (5), K (2), V (2) strips at this tick's index set, the plan's scalars, the state
+constexpr int kTickCarryLds = (kTickJ * 9 * (kTickNU + 1) + kTickJ * 12 + kTickNU + 1) * (int)sizeof(double);
 struct TickCarry {
     const double* blk;         // [B][NU][NU]   P(U'[p], U'[q]) before the previous tick's corrections
     const double* KU;          // [B][J][2][NU] K_s at U'
@@ -248,6 +249,13 @@ __device__ inline void predict_block(const View& v, const MotionStep& ms, const 
     }
 }
 
+#ifdef NUSLAM_CHAIN_CLOCK
+__device__ long long g_front_tl[16];          // debug builds: absolute 100 MHz stamps of one k_tick_front launch (TL below)
+#define TL(k, cond) do { if (cond) g_front_tl[k] = (long long)wall_clock64(); } while (0)
+__device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
+#else
+#define TL(k, cond) do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------------------ the next tick's start
 // P after the previous tick's corrections and this tick's predict, restricted to this tick's index set U' -- WITHOUT
 // waiting for the pass over P.  Correction s changes entry (a, b) of that 35 x 35 block through K_s(U'[a], :) and
@@ -263,22 +271,24 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
                                   double (*BKo)[kTickNU + 1], double* SMo, const int* ctrl4, int& seen, int& cached, int& brk,
                                   int& status)
 {
-    // 256 threads, and no more LDS than lets the chain's workgroup share a CU with one of the pass (112 KB): the prior
-    // rows R_s at U' of corrections 0..6 live in the scratch block FBs until the replay is over, those of 7..15 and the
-    // plan's scalars in 14.8 KB of dynamic LDS; a thread owns five entries of ONE row of the block and keeps that row's
-    // gains K_s in registers (M_s(U'[a], set_s) is formed from them per correction).
-    constexpr int NU = kTickNU, NT = 256, NE = 5, RS = 5 * (NU + 1);    // entries per thread; doubles per correction of R
-    constexpr int SPLIT = (NU * (NU + 1)) / RS;                         // corrections whose R fits the scratch block: 7
+    // 256 threads; a thread owns five entries of ONE row of the block.  What does not depend on the previous tick's strips is fetched
+    // BEFORE the wait for them (the plan's scalars); the strips at U' then come in as whole contiguous
+    // arrays, 16 bytes per lane (a CU's address path moves ~one lane-address per 2-3 cycles whatever the pattern: 12 k lane-loads --
+    // every thread its row's 32 gains -- were 12 of this function's 21 us), and V_s = H_s R_s at U' is formed ONCE per column
+    // (hp_entry, the strips' own definition) instead of once per entry.
+    constexpr int NU = kTickNU, NT = 256, NE = 5, RW = NU + 1;
     static_assert(NU % NE == 0 && (NU / NE) * NU <= NT, "five entries of one row per thread");
     const int tid = threadIdx.x;
     const TickStep* pl = cy.plan_prev + (size_t)b * kTickJ;
     const int Jt = cy.Jt;
     extern __shared__ double carry_lds[];
-    double* Rhi = carry_lds;                                            // [kTickJ - SPLIT][5][NU + 1]
-    double (*PS)[12] = reinterpret_cast<double (*)[12]>(carry_lds + (kTickJ - SPLIT) * RS);
-    double* SF = carry_lds + (kTickJ - SPLIT) * RS + kTickJ * 12;       // [NU + 1]
-    double* Rlo = &FBs[0][0];
+    double* Rl = carry_lds;                                             // [kTickJ][5][RW]  R_s(q, U'[p])
+    double* Kl = Rl + kTickJ * 5 * RW;                                  // [kTickJ][2][RW]  K_s(U'[p], r)
+    double* Vl = Kl + kTickJ * 2 * RW;                                  // [kTickJ][2][RW]  V_s(r, U'[p])
+    double (*PS)[12] = reinterpret_cast<double (*)[12]>(Vl + kTickJ * 2 * RW);
+    double* SF = Vl + kTickJ * 2 * RW + kTickJ * 12;                    // [RW]
     __shared__ int canon[NU + 1];
+    __shared__ int ndup_sh;
     // the arithmetic of the pass that is rewriting the covariance meanwhile: the exact chain (p1_entry) or the rank-2m sum
     const bool rank = cy.rank != 0 && !__syncthreads_or(tid < Jt && pl[tid < kTickJ ? tid : 0].init != 0);
 
@@ -293,42 +303,80 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
             if (U[k] == U[tid]) cp = k;
         canon[tid] = cp;
     }
-    __syncthreads();
-    // the strips at U' (compact, written by k_tick_panels through the position map) and the state there
-    for (int e = tid; e < kTickJ * 5 * NU; e += NT) {
-        const int st = e / (5 * NU), q = (e / NU) % 5, p = e % NU;
-        double* dst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
-        dst[q * (NU + 1) + p] = cy.RU[(((size_t)b * kTickJ + st) * 5 + q) * NU + canon[p]];
+    {
+        const unsigned long long dup = __ballot(tid < NU && canon[tid < NU ? tid : 0] != tid);      // (wave 0 holds all of them)
+        if (tid == 0) ndup_sh = __popcll(dup);
     }
-    if (tid < NU) SF[tid] = cy.SU[(size_t)b * NU + canon[tid]];
     const bool mine = tid < (NU / NE) * NU;
     const int a = mine ? tid / (NU / NE) : 0, b0 = mine ? (tid % (NU / NE)) * NE : 0;
     const int ia = U[a];
-    double K0[kTickJ], K1[kTickJ], E[NE];
-#pragma unroll
-    for (int st = 0; st < kTickJ; ++st) {
-        K0[st] = cy.KU[(((size_t)b * kTickJ + st) * 2 + 0) * NU + canon[a]];
-        K1[st] = cy.KU[(((size_t)b * kTickJ + st) * 2 + 1) * NU + canon[a]];
-    }
+    double E[NE];
+    TL(10, b == 0 && tid == 0);
+
+    // ---- the previous tick's strips at this tick's index set are complete
+    if (!tick_wait(cy.wait_cnt, cy.wait_target) && tid == 0) atomicAdd(cy.timeouts, 1);
+    TL(13, b == 0 && tid == 0);
+    // (the block prep gathered for this tick is on the handle's stream IN FRONT of those strips: complete as well)
 #pragma unroll
     for (int k = 0; k < NE; ++k) E[k] = cy.blk[(size_t)b * NU * NU + a * NU + b0 + k];
+    {
+        const Pack16<double>* r2 = reinterpret_cast<const Pack16<double>*>(cy.RU + (size_t)b * kTickJ * 5 * NU);
+        for (int e2 = tid; e2 < kTickJ * 5 * NU / 2; e2 += NT) {
+            const Pack16<double> w = r2[e2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * e2 + h, row = e / NU, p = e % NU;     // row = st * 5 + q
+                Rl[row * RW + p] = w.v[h];
+            }
+        }
+        const Pack16<double>* k2 = reinterpret_cast<const Pack16<double>*>(cy.KU + (size_t)b * kTickJ * 2 * NU);
+        for (int e2 = tid; e2 < kTickJ * 2 * NU / 2; e2 += NT) {
+            const Pack16<double> w = k2[e2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * e2 + h, row = e / NU, p = e % NU;     // row = st * 2 + r
+                Kl[row * RW + p] = w.v[h];
+            }
+        }
+        if (tid < NU) SF[tid] = cy.SU[(size_t)b * NU + canon[tid]];
+    }
     __syncthreads();
+    if (ndup_sh != 0) {
+        // an index that stands at several positions of U' (the same landmark seen twice, or ids out of range) has its strips at
+        // the first of them only (the position map keeps the first)
+        for (int p = 1; p < NU; ++p) {
+            const int cp = canon[p];
+            if (cp == p) continue;                                      // (uniform)
+            for (int row = tid; row < kTickJ * 7; row += NT) {
+                if (row < kTickJ * 5) Rl[row * RW + p] = Rl[row * RW + cp];
+                else Kl[(row - kTickJ * 5) * RW + p] = Kl[(row - kTickJ * 5) * RW + cp];
+            }
+        }
+        __syncthreads();
+    }
+    if (rank) {
+        for (int e = tid; e < kTickJ * 2 * NU; e += NT) {
+            const int row = e / NU, p = e % NU, st = row >> 1, r = row & 1;
+            double rs[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) rs[q] = Rl[(st * 5 + q) * RW + p];
+            Vl[row * RW + p] = hp_entry(PS[st], rs, r);
+        }
+        __syncthreads();
+    }
+    TL(11, b == 0 && tid == 0);
 
     if (rank) {
         // k_tick_rank's sum on these entries: acc = fma(V_f(column), -K_f(row), acc), f = 2 s + r ascending, as the f64 MFMA
         // accumulates it (a k-ordered fma chain); rounded to the storage type once, as that kernel stores it
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {
-            const double* ps = PS[st];
-            if (st < Jt && ps[11] == 0.0) {
-                const double* Rst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
+            if (st < Jt && PS[st][11] == 0.0) {
+                const double K0 = Kl[(st * 2 + 0) * RW + a], K1 = Kl[(st * 2 + 1) * RW + a];
 #pragma unroll
                 for (int k = 0; k < NE; ++k) {
-                    double r[5];
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) r[q] = Rst[q * (NU + 1) + b0 + k];
-                    E[k] = fma(hp_entry(ps, r, 0), -K0[st], E[k]);
-                    E[k] = fma(hp_entry(ps, r, 1), -K1[st], E[k]);
+                    E[k] = fma(Vl[(st * 2 + 0) * RW + b0 + k], -K0, E[k]);
+                    E[k] = fma(Vl[(st * 2 + 1) * RW + b0 + k], -K1, E[k]);
                 }
             }
         }
@@ -336,32 +384,32 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
         for (int k = 0; k < NE; ++k) E[k] = (double)(T)E[k];
     } else {
 #pragma unroll
-    for (int st = 0; st < kTickJ; ++st) {
-        const double* ps = PS[st];
-        if (st < Jt && ps[11] == 0.0) {                                 // (a skipped marker moves nothing in P)
-            const int c = (int)ps[10];
-            double m[5];
+        for (int st = 0; st < kTickJ; ++st) {
+            const double* ps = PS[st];
+            if (st < Jt && ps[11] == 0.0) {                             // (a skipped marker moves nothing in P)
+                const int c = (int)ps[10];
+                const double K0 = Kl[(st * 2 + 0) * RW + a], K1 = Kl[(st * 2 + 1) * RW + a];
+                double m[5];
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                double kh = 0.0;                                        // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
-                kh = fma(K0[st], ps[0 + 2 * q], kh);
-                kh = fma(K1[st], ps[1 + 2 * q], kh);
-                const int sidx = q < 3 ? q : c + (q - 3);
-                m[q] = (ia == sidx ? 1.0 : 0.0) - kh;
-            }
-            const double bef = (ia > 2 && ia < c) ? 1.0 : 0.0, aft = (ia > c + 1) ? 1.0 : 0.0;
-            const double* Rst = st < SPLIT ? Rlo + st * RS : Rhi + (st - SPLIT) * RS;
+                for (int q = 0; q < 5; ++q) {
+                    double kh = 0.0;                                    // gain_row's M(i, set[q]) = delta - (K H)(i, set[q])
+                    kh = fma(K0, ps[0 + 2 * q], kh);
+                    kh = fma(K1, ps[1 + 2 * q], kh);
+                    const int sidx = q < 3 ? q : c + (q - 3);
+                    m[q] = (ia == sidx ? 1.0 : 0.0) - kh;
+                }
+                const double bef = (ia > 2 && ia < c) ? 1.0 : 0.0, aft = (ia > c + 1) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < NE; ++k) {
-                double r[5];
+                for (int k = 0; k < NE; ++k) {
+                    double r[5];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) r[q] = Rst[q * (NU + 1) + b0 + k];
-                E[k] = p1_entry<T>(m, r, E[k], bef, aft);
+                    for (int q = 0; q < 5; ++q) r[q] = Rl[(st * 5 + q) * RW + b0 + k];
+                    E[k] = p1_entry<T>(m, r, E[k], bef, aft);
+                }
             }
         }
     }
-    }
-    __syncthreads();                                                    // (the scratch block held R until here)
+    TL(12, b == 0 && tid == 0);
     if (mine) {
 #pragma unroll
         for (int k = 0; k < NE; ++k) FBs[a][b0 + k] = E[k];
@@ -381,13 +429,6 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
 }
 
 // ------------------------------------------------------------------------------------------------ the serial chain
-#ifdef NUSLAM_CHAIN_CLOCK
-__device__ long long g_front_tl[16];          // debug builds: absolute 100 MHz stamps of one k_tick_front launch (TL below)
-#define TL(k, cond) do { if (cond) g_front_tl[k] = (long long)wall_clock64(); } while (0)
-__device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
-#else
-#define TL(k, cond) do { } while (0)
-#endif
 // FUSED: the workgroup first waits for the previous tick's strips, replays that tick's corrections on the 35 x 35 block
 // (what used to be a kernel of its own, k_tick_next: ~5 us of launch and one more hand-off per tick on the critical path
 // of the run) and applies this tick's predict to it (tick_carry), then runs the chain.
@@ -429,6 +470,9 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     TickStep* pl = plan + (size_t)b * kTickJ;
     const int J = o.J;
     TL(0, PUBLISH && b == 0 && tid == 0);                               // chain: entry
+    // The chain is the tick's critical path and one wave per SIMD; in overlapped runs waves of the pass over P share its CU: its
+    // instructions go first
+    __builtin_amdgcn_s_setprio(3);
 
     __shared__ double BK[2][NU][NU + 1];          // P(U[p], U[p']) before / after the current correction
     __shared__ double SM[2][NU + 1];              // state at U
@@ -453,8 +497,8 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     __syncthreads();
     int seen = 0, brk = 0, status = 0, cached = 0;
     if (FUSED) {
-        if (!tick_wait(cy.wait_cnt, cy.wait_target) && tid == 0) atomicAdd(cy.timeouts, 1);
-        tick_carry<T>(v, b, cy, Ush, BK[1], BK[0], SM[0], ctrl_out4, seen, cached, brk, status);
+        tick_carry<T>(v, b, cy, Ush, BK[1], BK[0], SM[0], ctrl_out4, seen, cached, brk, status);    // (waits, inside, for the previous tick's strips)
+        TL(14, PUBLISH && b == 0 && tid == 0);                          // ... and replayed on this tick's block
     } else {
         // Everything the round starts from is REQUESTED first -- this tick's twist and heading, the markers, the control words, the
         // 35 x 35 block -- and what does not need the block is computed while it is on its way: the motion step's sines and
@@ -1245,8 +1289,12 @@ template <typename T>
 __device__ inline void tick_panels_stream(const int b, const int wg, View v, TickObs o, const T* __restrict__ P,
                                           const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                           double* __restrict__ Rbuf, double* __restrict__ Vbuf, TickPublish pub,
-                                          int* __restrict__ timeouts)
+                                          int* __restrict__ timeouts, const int* __restrict__ posmap = nullptr,
+                                          double* __restrict__ KU = nullptr, double* __restrict__ RU = nullptr,
+                                          double* __restrict__ SU = nullptr)
 {
+    // posmap != null (streamed overlapped runs, k_tick_strips): the strips at the NEXT tick's index set are also dropped into the
+    // compact arrays KU, RU, SU for that tick's chain (tick_carry), as k_tick_panels does
     constexpr int NU = kTickNU, IDX = 32;
     const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x / (IDX * 4));
     const int k = threadIdx.x & 3;
@@ -1281,6 +1329,9 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     const int tr = live ? t : 0;
     const bool owner = live && k == 0;
     double* const dump = v.dump + (threadIdx.x & (kTickDump - 1));
+    const int pm = (posmap && owner) ? posmap[(size_t)b * ld + t] : -1;
+    double* const cu_dst = pm < 0 ? dump : role == 0 ? RU + (size_t)b * kTickJ * 5 * NU + pm : KU + (size_t)b * kTickJ * 2 * NU + pm;
+    const size_t cu_step = pm >= 0 ? (size_t)NU : 0;
     double PN[kQuadRows];
     double sv = 0.0;
     bool failed = false;
@@ -1377,6 +1428,10 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                         const size_t rsp = owner ? (size_t)ld : 0;
 #pragma unroll
                         for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
+                        if (posmap) {                                   // (uniform)
+#pragma unroll
+                            for (int q = 0; q < 5; ++q) cu_dst[(size_t)(st * 5 + q) * cu_step] = rs[q];
+                        }
                         if (Vbuf) {
                             double* const vd = owner ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : dump;
 #pragma unroll
@@ -1413,6 +1468,10 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                         const size_t ksp = owner ? (size_t)ld : 0;
                         kd[(size_t)(st * 2 + 0) * ksp] = K[0];
                         kd[(size_t)(st * 2 + 1) * ksp] = K[1];
+                        if (posmap) {                                   // (uniform)
+                            cu_dst[(size_t)(st * 2 + 0) * cu_step] = K[0];
+                            cu_dst[(size_t)(st * 2 + 1) * cu_step] = K[1];
+                        }
                         const double bef = (t > 2 && t < c) ? 1.0 : 0.0, aft = (t > c + 1) ? 1.0 : 0.0;
                         double s0 = (init && t == c) ? ps->lxy[0] : (init && t == c + 1) ? ps->lxy[1] : sv;
                         double acc = 0.0;
@@ -1449,6 +1508,37 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         }
     }
     if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
+    if (role == 1 && pm >= 0) SU[(size_t)b * NU + pm] = sv;
+}
+
+// The strips as a launch of their own that FOLLOWS a chain running in another launch (on the chain stream of a streamed overlapped
+// run, nuslam_hip.hip): the same consumer as k_tick_front's strip workgroups, behind predict(t) and prep(t) on the handle's
+// stream; drops the strips at the next tick's index set for that tick's chain and counts itself done for it.
+template <typename T>
+__global__ __launch_bounds__(256) void k_tick_strips(View v, TickObs o, const T* __restrict__ P, const TickStep* __restrict__ plan,
+                                                     double* __restrict__ Kbuf, double* __restrict__ Rbuf, double* __restrict__ Vbuf,
+                                                     TickPublish pub, int* __restrict__ timeouts, const int* __restrict__ posmap,
+                                                     double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU,
+                                                     int* __restrict__ done_cnt)
+{
+    TL(6, blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    TL(8, blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
+    tick_panels_stream<T>(blockIdx.y, blockIdx.x, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts, posmap, KU, RU, SU);
+    if (done_cnt) {
+        __syncthreads();
+        if (threadIdx.x == 0) tick_signal(done_cnt);
+    }
+    TL(7, blockIdx.y == 0 && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0);
+    TL(9, blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0);
+}
+
+// ... and the chain it follows: k_tick_chain announcing its plan entry by entry (FUSED: started from the previous tick's strips)
+template <typename T, bool FUSED>
+__global__ __launch_bounds__(256) void k_tick_chain_pub(View v, TickObs o, int total_landmarks, const T* __restrict__ P,
+                                                        TickStep* __restrict__ plan, TickCarry cy, int* __restrict__ ctrl_out4,
+                                                        int* __restrict__ done_cnt, TickPublish pub)
+{
+    tick_chain<T, FUSED, true>(blockIdx.x, v, o, total_landmarks, P, plan, cy, ctrl_out4, done_cnt, pub);
 }
 
 // The tick's predict as workgroups of k_tick_front (thread t: column t of rows 1, 2, row t of columns 1, 2, state entry t; thread

@@ -990,6 +990,8 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
         HIPCHK(hipMalloc(&h->tk_plan2, sizeof(TickStep) * B * kTickJ));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain_pub<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_chain_pub<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kTickCarryLds));
         HIPCHK(hipMalloc(&h->tk_ctrl4, sizeof(int) * 4 * B));
         HIPCHK(hipMalloc(&h->tk_blk, sizeof(double) * 2 * B * kTickNU * kTickNU));      // two: by the parity of the tick that reads it
         HIPCHK(hipMalloc(&h->tk_posmap, sizeof(int) * B * h->ld));
@@ -1036,6 +1038,13 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
     int* timeouts = h->tk_sync + 2;
     int rc = NUSLAM_OK;
     int prev_J = 0;
+    // STREAMED (few filters: the chains' and the strips' workgroups fit the chip together): the strips of tick t are a launch on the
+    // handle's stream that FOLLOWS chain(t), running on the chain stream, plan entry by plan entry (TickPublish, as inside
+    // k_tick_front) instead of starting when it has ended, and counts itself done for chain(t+1), which is already waiting
+    // on its CU.  The loop that bounds a tick is then chain -> (last entry's strips) -> chain, ~38 us at N = 1000, with the pass
+    // over P, the next predict and prep entirely beside it.
+    const int n_strip = (h->ld + 31) / 32;
+    const bool streamed = h->tick_mode != 3 && (long long)(n_strip + 1) * h->B <= h->n_cu;
     for (int t = t_begin; t < t_end; ++t) {
         TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
         const bool more = t + 1 < t_end;
@@ -1050,12 +1059,19 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
                                                 h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m,
                                                 (long long)h->tr_ticks * h->tr_m, h->tr_m, total);
 
+        TickPublish pub;
+        pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = 0; pub.gbase = pub.pbase = 0;
+        pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0;
         // ---- chain stream: chain(t): from P for the first tick (behind predict), from the strips of tick t-1 afterwards
         if (t == t_begin) {
             HIPCHK(hipEventRecord(h->ov_start, h->stream));               // once per run
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ov_start, 0));
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
-                                          total, (const T*)h->P(), plan, TickCarry{}, h->tk_ctrl4, cnt_chain)));
+            if (streamed)
+                DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain_pub<T, false>, dim3(h->B), dim3(256), 0, v, o,
+                                              total, (const T*)h->P(), plan, TickCarry{}, h->tk_ctrl4, cnt_chain, pub)));
+            else
+                DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), 0, v, o,
+                                              total, (const T*)h->P(), plan, TickCarry{}, h->tk_ctrl4, cnt_chain)));
         } else {
             // (it waits, inside, for the strips of tick t-1 at this tick's index set: cnt_next counts the signal kernels
             // enqueued behind k_tick_panels)
@@ -1071,12 +1087,43 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
                 rc = launch_on(h, h->stream2, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_next, h->seq_next, timeouts, 1 << 18);
                 if (rc) return rc;
             }
-            DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256),
-                                          (size_t)kTickCarryLds, v, o, total, (const T*)h->P(), plan, cy, h->tk_ctrl4, cnt_chain)));
+            if (streamed)
+                DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain_pub<T, true>, dim3(h->B), dim3(256),
+                                              (size_t)kTickCarryLds, v, o, total, (const T*)h->P(), plan, cy, h->tk_ctrl4, cnt_chain, pub)));
+            else
+                DISPATCH_T(h, rc = (launch_on(h, h->stream2, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, true>, dim3(h->B), dim3(256),
+                                              (size_t)kTickCarryLds, v, o, total, (const T*)h->P(), plan, cy, h->tk_ctrl4, cnt_chain)));
         }
         prev_J = o.J;
         if (rc) return rc;
         h->seq_chain += h->B;
+        if (streamed) {
+            // ---- handle's stream: prep(t), the strips following chain(t) (every workgroup counts itself done for chain(t+1)), the pass
+            h->seq_pub += 2u * kTickJ;
+            if (more) {
+                DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 1, h->B), dim3(64), v, o, obs_of(t + 1),
+                                           (const T*)h->P(), h->tk_posmap, h->tk_blk + (size_t)((t + 1) & 1) * B * kTickNU * kTickNU,
+                                           (const int*)cnt_chain, h->seq_chain, timeouts)));
+                if (rc) return rc;
+            }
+            double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
+            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_PANELS, k_tick_strips<T>, dim3(n_strip, h->B), dim3(256), v, o, (const T*)h->P(),
+                                       (const TickStep*)plan, h->tk_K, h->tk_R, vbuf, pub, timeouts, (const int*)(more ? h->tk_posmap : nullptr),
+                                       h->tk_KU, h->tk_RU, h->tk_SU, more ? cnt_next : (int*)nullptr)));
+            if (rc) return rc;
+            if (more) h->seq_next += n_strip * h->B;
+            else {
+                // (the run's last chain has written the control words too before anything else on this stream goes on)
+                rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_chain, h->seq_chain, timeouts, 1 << 18);
+                if (rc) return rc;
+            }
+            rc = launch_pass(h, v, o.J, plan, more, may_init, whole(h));
+            if (rc) return rc;
+            h->sidx ^= 1;
+            h->cidx ^= 1;
+            h->pidx ^= 1;
+            continue;
+        }
         // ---- handle's stream: prep(t) (its last workgroup waits for plan(t)), strips(t), the signal, the pass over P
         if (more)
             DISPATCH_T(h, rc = (launch(h, -1, k_tick_prep<T>, dim3(kTickNU + 2, h->B), dim3(64), v, o, obs_of(t + 1),

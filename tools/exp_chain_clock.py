@@ -12,6 +12,8 @@ bx, by, wid = synth.warmup_observations(tr.landmarks)
 ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT)
 ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
 bt = ekf.as_batch()
+if os.environ.get("OVERLAP"):
+    bt.set_overlap(True)
 if os.environ.get("CHAIN_ONLY"):
     bt.set_tick_mode(1)        # k_tick_chain as a launch of its own (plain plan stores) instead of k_tick_front's workgroup 0
 bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
@@ -20,8 +22,8 @@ L = nh.lib(); L.nuslam_debug_chain_clock.argtypes = [C.POINTER(C.c_longlong)]
 acc = []
 tls = []
 L.nuslam_debug_front_timeline.argtypes = [C.POINTER(C.c_longlong)]
-for t in range(30, 40):
-    bt.run(t, t + 1); bt.sync()
+for t in range(30, 40, 2 if os.environ.get("OVERLAP") else 1):
+    bt.run(t, t + (2 if os.environ.get("OVERLAP") else 1)); bt.sync()
     out = (C.c_longlong * 32)(); L.nuslam_debug_chain_clock(out); acc.append(list(out))
     tl = (C.c_longlong * 16)(); L.nuslam_debug_front_timeline(tl); tls.append(list(tl))
 raw = np.median(np.array(acc, dtype=np.float64), axis=0).reshape(4, 8)
@@ -41,4 +43,4 @@ if not os.environ.get("CHAIN_ONLY"):
     med = np.median(t, axis=0)
     print("k_tick_front timeline (us after the chain workgroup's entry): chain loop start %.2f, loop end %.2f, exit %.2f | predict workgroup %.2f .. %.2f"
           " | strips: middle workgroup %.2f .. %.2f, last workgroup %.2f .. %.2f" % tuple(med[1:10]))
-    print("   chain prologue: block gathered and predict applied %.2f" % med[10])
+    print("   chain prologue: block gathered and predict applied %.2f | overlapped runs: previous strips complete %.2f, replayed on the block %.2f (plan scalars %.2f, strips loaded %.2f, replay %.2f)" % (med[10], med[13], med[14], med[10], med[11], med[12]))
