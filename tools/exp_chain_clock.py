@@ -15,7 +15,7 @@ bt = ekf.as_batch()
 if os.environ.get("OVERLAP"):
     bt.set_overlap(True)
 if os.environ.get("CHAIN_ONLY"):
-    bt.set_tick_mode(1)        # k_tick_chain as a launch of its own (plain plan stores) instead of k_tick_front's workgroup 0
+    bt.set_tick_mode(3)        # k_tick_chain as a launch of its own (plain plan stores) instead of k_tick_front's workgroup 0
 bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
 bt.run(0, 30); bt.sync()
 L = nh.lib(); L.nuslam_debug_chain_clock.argtypes = [C.POINTER(C.c_longlong)]
