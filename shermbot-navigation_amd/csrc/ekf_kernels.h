@@ -110,12 +110,11 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
     const double theta = s[0];
     const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
     const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
-    // bookkeeping == 2 (pipelined runs): the covariance only -- state vector and control words travel with the front launches
-    if (t < v.ld && bookkeeping != 2) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
+    if (t < v.ld) so[t] = t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t];
 
     if (STATE_ONLY) {
         if (t == 0 && Fa && b == 0) { Fa[1] = (T)a1; Fa[2] = (T)a2; }
-        if (t == 0 && bookkeeping == 1) {
+        if (t == 0 && bookkeeping) {
             const int* ci = v.c_in + b * C_WORDS;
             int* co = v.c_out + b * C_WORDS;
             co[C_SEEN] = ci[C_SEEN]; co[C_SEEN_CACHED] = ci[C_SEEN]; co[C_BRK] = 0; co[C_STATUS] = ci[C_STATUS];
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(256) void k_predict(View v, TwistArg tw, T* __restr
             for (int i = 0; i < 3; ++i) Pb[(size_t)j * ld + i] = (T)(u[i][j] + v.Q[i + 3 * j]);
         // slam.cpp:250-251: the caller caches seen_landmarks at the top of the loop body; a new tick also
         // clears the `break` of the previous marker loop.
-        if (bookkeeping == 1) {
+        if (bookkeeping) {
             const int* ci = v.c_in + b * C_WORDS;
             int* co = v.c_out + b * C_WORDS;
             co[C_SEEN] = ci[C_SEEN];
@@ -347,7 +346,6 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 #include "ekf_update2.h"
 #include "ekf_tick.h"
 #include "ekf_rank.h"
-#include "ekf_pipe.h"
 #include "ekf_da.h"
 #include "ekf_updatej.h"
 #include "ekf_deferred.h"

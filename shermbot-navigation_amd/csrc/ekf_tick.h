@@ -438,16 +438,9 @@ __device__ inline void tick_carry(const View& v, int b, const TickCarry& cy, con
 struct TickPublish {
     int* flag;             // per filter, kPubWords ints: [0] pub_base + number of complete plan entries of this round;
     int base;              // (predict fused in, below) [1] the chain has gathered its block, [2] predict workgroups done
-    int predict;           // 1: this launch also holds the tick's predict (k_tick_front's middle workgroups)
-                           // 2 (pipelined runs): chain and strips start from the PANELS below (k_tick_panel_carry, ekf_pipe.h), which
-                           // hold the covariance at the round's index set after predict; the chain does the tick's bookkeeping
+    int predict;           // != 0: this launch also holds the tick's predict (k_tick_front's middle workgroups)
     int gbase, pbase;      // the values [1] / [2] reach when that has happened
     TwistArg tw;
-    const double* prow;    // [B][kTickNU][ld] prow[p][t] = P(U[p], t)
-    const double* pcol;    // [B][kTickNU][ld] pcol[p][t] = P(t, U[p])
-    const double* pstate;  // [B][ld]
-    int* start_cnt;        // (pipelined runs; may be null) every workgroup of the launch counts itself RESIDENT here at its entry: the other
-                           // stream starts its pass over P only then, so that its workgroups do not take the chip first
 };
 constexpr int kPubWords = 4;
 __device__ inline void plan_store(bool publish, double* p, double x)
@@ -510,9 +503,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         // Everything the round starts from is REQUESTED first -- this tick's twist and heading, the markers, the control words, the
         // 35 x 35 block -- and what does not need the block is computed while it is on its way: the motion step's sines and
         // cosines (motion_step), the markers' polar forms.
-        const bool fpred = PUBLISH && pub.predict == 1;                 // the tick's predict runs in THIS launch (k_tick_front)
-        const bool fpan = PUBLISH && pub.predict == 2;                  // pipelined runs: block and pose from the panels
-        const double* prow = fpan ? pub.prow + (size_t)b * NU * ld : nullptr;
+        const bool fpred = PUBLISH && pub.predict;                      // the tick's predict runs in THIS launch (k_tick_front)
         double dth = 0.0, dxx = 0.0, theta = 0.0;
         if (fpred) {
             const TwistArg& tw = pub.tw;
@@ -535,7 +526,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
             const int e = tid + 256 * u, ec = e < NU * NU ? e : 0;
             const int q = ec / NU, p = ec % NU;
-            g[u] = fpan ? prow[(size_t)p * ld + Ush[q]] : (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+            g[u] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
             // fpred: the entry of row 0 (column 0) predict combines it with (predict_block's column / row role), fetched by the
             // thread itself so that predict can be applied before anything passes through LDS
             gp[u] = 0.0;
@@ -546,7 +537,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         }
         double gc = 0.0;                                                // the 3 x 3 pose corner, entry (i, j) on lane i + 3 j of wave 0
         if (fpred && tid < 9) gc = (double)Pb[(size_t)(tid / 3) * ld + tid % 3];
-        const double gs = fpan ? pub.pstate[(size_t)b * ld + Ush[tid < NU ? tid : 0]] : s[Ush[tid < NU ? tid : 0]];
+        const double gs = s[Ush[tid < NU ? tid : 0]];
         MotionStep ms{};
         if (fpred) ms = motion_step(theta, dth, dxx);
         if (wave == 3 && lane < kTickJ) {         // all markers' polar forms at once, one lane each
@@ -607,8 +598,8 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             __syncthreads();                                            // (every gathered value has arrived: the predict workgroups may go)
             TL(10, b == 0 && tid == 0);                                 // chain: block gathered, predict applied
             if (tid == 0) st_agent(pub.flag + kPubWords * b + 1, pub.gbase);
+            cached = seen; brk = 0;                                     // the tick's bookkeeping (slam.cpp:250-251)
         }
-        if (fpred || fpan) { cached = seen; brk = 0; }                  // the tick's bookkeeping (slam.cpp:250-251)
     }
     if (FUSED && wave == 3 && lane < kTickJ) {    // (overlapped runs: the markers' polar forms)
         double a = 0.0, bb = 0.0;
@@ -1344,16 +1335,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     double PN[kQuadRows];
     double sv = 0.0;
     bool failed = false;
-    if (pub.predict == 2) {
-        // pipelined runs: the panels hold this lane's entries, position by position
-        const double* pan = (role == 0 ? pub.prow : pub.pcol) + (size_t)b * NU * ld;
-#pragma unroll
-        for (int j = 0; j < kQuadRows; ++j) {
-            const int p = 4 * j + k;
-            PN[j] = pan[(size_t)(p < NU ? p : 0) * ld + tr];
-        }
-        if (role == 1) sv = pub.pstate[(size_t)b * ld + tr];
-    } else if (pub.predict) {
+    if (pub.predict) {
         // the tick's predict is being applied by workgroups of this launch: wait for all of them, then read what they wrote
         // (rows / columns 1, 2 of P, the advanced state in s_out) with agent-scope loads -- every load of handed-off bytes
         if (threadIdx.x == 0) {
@@ -1625,12 +1607,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total_landmarks, T* __restrict__ P,
                                                     TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                     double* __restrict__ Rbuf, double* __restrict__ Vbuf,
-                                                    TickPublish pub, int n_pred, int* __restrict__ timeouts, int* __restrict__ done_cnt)
+                                                    TickPublish pub, int n_pred, int* __restrict__ timeouts)
 {
-    // done_cnt (pipelined runs; may be null): every workgroup counts itself done behind its stores -- for the pass over P on the other stream
     const int b = blockIdx.y;
     const int x = blockIdx.x;
-    if (pub.start_cnt && threadIdx.x == 0) __hip_atomic_fetch_add(pub.start_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (x == 0) tick_chain<T, false, true>(b, v, o, total_landmarks, P, plan, TickCarry{}, nullptr, nullptr, pub);
     else if (x <= n_pred) {
         TL(4, b == 0 && x == 1 && threadIdx.x == 0);                    // predict role: entry / exit
@@ -1644,10 +1624,6 @@ __global__ __launch_bounds__(256) void k_tick_front(View v, TickObs o, int total
         tick_panels_stream<T>(b, x - 1 - n_pred, v, o, P, plan, Kbuf, Rbuf, Vbuf, pub, timeouts);
         TL(7, b == 0 && x == mid && threadIdx.x == 0);
         TL(9, b == 0 && x == last && threadIdx.x == 0);
-    }
-    if (done_cnt) {
-        __syncthreads();
-        if (threadIdx.x == 0) tick_signal(done_cnt);
     }
 }
 

@@ -130,11 +130,6 @@ struct nuslam_batch {
     int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
     int* tk_posmap = nullptr; double* tk_KU = nullptr; double* tk_RU = nullptr; double* tk_SU = nullptr;
     int seq_chain = 0, seq_next = 0;                   // the counters' values after everything enqueued so far
-    // pipelined runs (run_pipelined): the panels a tick starts from, the second set of K / V strips, the streams' counters
-    double* pn_row = nullptr; double* pn_col = nullptr; double* pn_state = nullptr;
-    double* tk_K2 = nullptr; double* tk_V2 = nullptr;
-    int seq_pa = 0, seq_pb = 0, seq_ps = 0;
-    hipStream_t stream_lo = nullptr;                   // pass and predict of pipelined runs: LOWEST priority (the front launches go first)
     hipEvent_t ov_start = nullptr;
     std::vector<hipEvent_t> ov_events;
     bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
@@ -609,17 +604,13 @@ int launch_pass(nuslam_batch* h, const View& v, int J, const TickStep* plan, boo
 // a landmark counts as corrected once a known-id marker for it has certainly reached update() -- resolve(): 1 <= id <= n,
 // the marker loop not broken, id <= total_landmarks (above it the marker is either a first sighting or the `break`,
 // slam.cpp:295-316, which the host cannot tell apart: it then stops marking for the rest of the tick).
-bool tick_may_init_on(unsigned char* tb, int n, const int* ids, int m, int total);
 bool tick_may_init(nuslam_batch* h, int b, const int* ids, int m, int total)
 {
-    return tick_may_init_on(h->touched.data() + (size_t)b * (h->n + 1), h->n, ids, m, total);
-}
-bool tick_may_init_on(unsigned char* tb, int n, const int* ids, int m, int total)
-{
+    unsigned char* tb = h->touched.data() + (size_t)b * (h->n + 1);
     bool may = false, maybe_brk = false;
     for (int i = 0; i < m; ++i) {
         const int id = ids[i];
-        if (id < 1 || id > n) continue;                    // skipped marker / bad id: nothing is applied
+        if (id < 1 || id > h->n) continue;                 // skipped marker / bad id: nothing is applied
         if (!tb[id]) may = true;
         if (maybe_brk) continue;
         if (id > total) { maybe_brk = true; continue; }
@@ -755,11 +746,10 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             TickPublish pub;
             pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = with_predict ? 1 : 0;
             pub.gbase = (int)(h->seq_gather + 1u); pub.pbase = (int)(h->seq_pred + (unsigned)n_pred);
-            pub.prow = pub.pcol = pub.pstate = nullptr; pub.start_cnt = nullptr;
             if (with_predict) pub.tw = *fused_predict;
             else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
-                                       (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2, (int*)nullptr)));
+                                       (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
             if (rc) return rc;
             h->seq_pub += 2u * kTickJ;
             if (with_predict) { h->seq_gather += 1u; h->seq_pred += (unsigned)n_pred; }
@@ -974,10 +964,22 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     return NUSLAM_OK;
 }
 
-// the second stream of overlapped / pipelined runs and what both kinds share; probes once per handle whether two streams really run side
-// by side here (h->ov_ok)
-int ensure_overlap(nuslam_batch* h)
+// nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
+// tick's markers while it enqueues this one.  Two free-running streams, no event between them inside the loop (a
+// cross-stream hipEvent cost 10-20 us per use here); the two hand-offs per tick are counters in device memory
+// (tick_signal / tick_wait):
+//   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> signal -> pass(t)         (P, state vector)
+//   chain stream      [strips(t-1)] chain(t) -> [strips(t)] chain(t+1) -> ...                 (a 35 x 35 block)
+// prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read -- into the
+// block buffer of tick t+1's parity: chain(t+1) reads it at its start, while prep(t+1) (which only its LAST workgroup holds
+// back until chain(t+1) is done) already writes the other one; strips(t)
+// also drops the gain / prior-row strips at that set into compact arrays; chain(t+1) -- one kernel, waiting inside for
+// the signal behind strips(t) -- first replays the round on the block and applies predict(t+1) (tick_carry), then runs
+// its corrections: all while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic, same bits as the one-stream order
+// (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
+int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
 {
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
     const size_t B = (size_t)h->B;
     if (!h->stream2) {
         // its own hardware queue, served first: a chain is one workgroup per filter
@@ -1014,27 +1016,6 @@ int ensure_overlap(nuslam_batch* h)
         HIPCHK(hipMemcpy(&gave_up, h->tk_sync + 4, sizeof(int), hipMemcpyDeviceToHost));
         h->ov_ok = gave_up ? 0 : 1;
     }
-    return NUSLAM_OK;
-}
-
-// nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
-// tick's markers while it enqueues this one.  Two free-running streams, no event between them inside the loop (a
-// cross-stream hipEvent cost 10-20 us per use here); the two hand-offs per tick are counters in device memory
-// (tick_signal / tick_wait):
-//   handle's stream   predict(t), prep(t) -> [plan(t)] strips(t) -> signal -> pass(t)         (P, state vector)
-//   chain stream      [strips(t-1)] chain(t) -> [strips(t)] chain(t+1) -> ...                 (a 35 x 35 block)
-// prep(t) gathers the 35 x 35 block at the NEXT tick's index set out of the covariance pass(t) will read -- into the
-// block buffer of tick t+1's parity: chain(t+1) reads it at its start, while prep(t+1) (which only its LAST workgroup holds
-// back until chain(t+1) is done) already writes the other one; strips(t)
-// also drops the gain / prior-row strips at that set into compact arrays; chain(t+1) -- one kernel, waiting inside for
-// the signal behind strips(t) -- first replays the round on the block and applies predict(t+1) (tick_carry), then runs
-// its corrections: all while pass(t), predict(t+1), prep(t+1) run.  Same arithmetic, same bits as the one-stream order
-// (tests/test_gpu_tick.py::test_overlapped_run_is_bit_identical).
-int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
-{
-    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
-    const size_t B = (size_t)h->B;
-    { int erc = ensure_overlap(h); if (erc) return erc; }
     if (!h->ov_ok) return kNotConcurrent;             // (internal: the caller falls back to the one-stream loop)
     HIPCHK(hipMemsetAsync(h->tk_posmap, 0xff, sizeof(int) * B * h->ld, h->stream));      // every index: not in the next tick's set
     auto obs_of = [&](int t) {
@@ -1080,7 +1061,6 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
 
         TickPublish pub;
         pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = 0; pub.gbase = pub.pbase = 0;
-        pub.prow = pub.pcol = pub.pstate = nullptr; pub.start_cnt = nullptr;
         pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0;
         // ---- chain stream: chain(t): from P for the first tick (behind predict), from the strips of tick t-1 afterwards
         if (t == t_begin) {
@@ -1167,153 +1147,13 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
     return NUSLAM_OK;
 }
 
-// nuslam_batch_run PIPELINED (one filter or few, known ids, warm map, the rank-2m pass): the front launch of tick t (chain + strips,
-// k_tick_front) starts from PANELS that k_tick_panel_carry forms from the covariance the pass of tick t-1 READS and that tick's
-// strips (ekf_pipe.h) -- so the pass over P of tick t-1 and the predict of tick t run on a second stream BESIDE the front launch of
-// tick t instead of in front of it.  What bounds a tick is then panels + front launch alone.
-//   handle's stream   panels(t) -> front(t) -> panels(t+1) -> front(t+1) ...
-//   second stream     [front(t) done, front(t+1) resident] pass(t) -> predict(t+1) (covariance only) -> signal ...
-// panels(t) waits for the second stream's signal of tick t-2 (what front(t) overwrites has been read by then): the second stream
-// may lag a whole tick.  The pass starts only when the NEXT front launch is resident: its thousands of workgroups would otherwise
-// take every CU before that launch's seventy got one.
-// Same arithmetic on every number as the one-stream order: same bits (tests/test_gpu_tick.py).  Returns kNotConcurrent when the
-// run does not qualify (a tick that may hold a first sighting, streams that do not run side by side): the caller takes the usual loop.
-int run_pipelined(nuslam_batch* h, int t_begin, int t_end, int total)
-{
-    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
-    { int erc = ensure_overlap(h); if (erc) return erc; }
-    if (!h->ov_ok || h->stream2 == h->stream) return kNotConcurrent;
-    const size_t B = (size_t)h->B;
-    const int m = h->tr_m;
-    auto ids_of = [&](int b, int t) {
-        return !h->h_ids.empty() ? h->h_ids.data() + (size_t)t * m : h->h_ids_pf.data() + ((size_t)b * h->tr_ticks + t) * m;
-    };
-    // every tick of the run provably without a first sighting (on a copy of the host's bitmap: nothing is marked if the run is refused)
-    {
-        std::vector<unsigned char> tb(h->touched);
-        for (int t = t_begin; t < t_end; ++t)
-            for (int b = 0; b < h->B; ++b)
-                if (tick_may_init_on(tb.data() + (size_t)b * (h->n + 1), h->n, ids_of(b, t), m, total)) return kNotConcurrent;
-    }
-    if (!h->stream_lo) {
-        int prio_lo = 0, prio_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream_lo, hipStreamNonBlocking, prio_lo));
-    }
-    const hipStream_t sb = h->stream_lo;
-    if (!h->pn_row) {
-        HIPCHK(hipMalloc(&h->pn_row, sizeof(double) * B * kTickNU * h->ld));
-        HIPCHK(hipMalloc(&h->pn_col, sizeof(double) * B * kTickNU * h->ld));
-        HIPCHK(hipMalloc(&h->pn_state, sizeof(double) * B * h->ld));
-        HIPCHK(hipMalloc(&h->tk_K2, sizeof(double) * (B * kTickJ * 2 * h->ld + kTickDump)));
-        HIPCHK(hipMalloc(&h->tk_V2, sizeof(double) * B * kTickJ * 2 * h->ld));
-        HIPCHK(hipMemsetAsync(h->tk_K2, 0, sizeof(double) * (B * kTickJ * 2 * h->ld + kTickDump), h->stream));
-        HIPCHK(hipMemsetAsync(h->tk_V2, 0, sizeof(double) * B * kTickJ * 2 * h->ld, h->stream));
-    }
-    auto obs_of = [&](int t) {
-        ObsArg o;
-        o.a = h->tr_mx; o.b = h->tr_my; o.ids = h->tr_ids;
-        o.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * h->tr_m;
-        o.off = (long long)t * h->tr_m;
-        o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
-        const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
-        return make_tick_obs(h, o, 0, h->tr_m, hid, nullptr, nullptr);
-    };
-    auto twist_of = [&](int t) {
-        TwistArg tw;
-        tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
-        tw.dth0 = tw.dx0 = 0.0;
-        return tw;
-    };
-    int* cnt_a = h->tk_sync + 5;          // bumped by every workgroup of a front launch behind its stores
-    int* cnt_b = h->tk_sync + 6;          // bumped behind each predict (and the last pass) on the second stream
-    int* cnt_s = h->tk_sync + 7;          // bumped by every workgroup of a front launch at its ENTRY
-    int* timeouts = h->tk_sync + 2;
-    const int n_strip = (h->ld + 31) / 32;
-    const int n_front = (1 + n_strip) * h->B;
-    const dim3 pc_grid((unsigned)((h->ld + 63) / 64 + 1), 2, (unsigned)h->B);
-    const Sub other{ 0, h->B, sb };
-    int rc = NUSLAM_OK;
-    // the second stream starts behind everything the handle's stream holds
-    HIPCHK(hipEventRecord(h->ov_start, h->stream));
-    HIPCHK(hipStreamWaitEvent(sb, h->ov_start, 0));
-    const PanelSet pset{ h->pn_row, h->pn_col, h->pn_state };
-    const TickStep* plan_prev = h->tk_plan;
-    int prev_J = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-        TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
-        const bool more = t + 1 < t_end;
-        const TickObs o = obs_of(t);
-        for (int b = 0; b < h->B; ++b) (void)tick_may_init(h, b, ids_of(b, t), m, total);      // (mark the ids as corrected)
-        // ---- handle's stream: the panels tick t starts from
-        if (t == t_begin) {
-            // the run's first tick: predict as usual, the panels are plain copies of the covariance's rows and columns
-            rc = do_predict(h, twist_of(t));
-            if (rc) return rc;
-            const View v = h->view();
-            DISPATCH_T(h, rc = (launch(h, -1, k_tick_panel_carry<T>, pc_grid, dim3(64), v, o, (const T*)h->P(), (const TickStep*)plan_prev, 0,
-                                       (const double*)h->tk_K, (const double*)h->tk_V, twist_of(t), 0, (const double*)v.s_in, pset,
-                                       (const int*)nullptr, 0, timeouts)));
-        } else {
-            // from the covariance the pass of tick t-1 reads (the other buffer: the flip is already done) and that tick's strips
-            // (swapped below: tk_K2 / tk_V2 hold them now); waits for the second stream's signal of tick t-2
-            const View v = h->view();
-            DISPATCH_T(h, rc = (launch(h, -1, k_tick_panel_carry<T>, pc_grid, dim3(64), v, o, (const T*)h->Palt(), plan_prev, prev_J,
-                                       (const double*)h->tk_K2, (const double*)h->tk_V2, twist_of(t), 1, (const double*)v.s_in, pset,
-                                       (const int*)cnt_b, h->seq_pb - 1, timeouts)));
-        }
-        if (rc) return rc;
-        // ---- handle's stream: chain + strips of tick t from the panels
-        const View v = h->view();
-        TickPublish pub;
-        pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = 2; pub.gbase = pub.pbase = 0;
-        pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0;
-        pub.prow = h->pn_row; pub.pcol = h->pn_col; pub.pstate = h->pn_state; pub.start_cnt = cnt_s;
-        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_strip, h->B), dim3(256), v, o, total,
-                                   (T*)h->P(), plan, h->tk_K, h->tk_R, h->tk_V, pub, 0, timeouts, cnt_a)));
-        if (rc) return rc;
-        h->seq_pub += 2u * kTickJ;
-        h->seq_pa += n_front;
-        h->seq_ps += n_front;
-        // ---- second stream: behind this front launch (and with the next one resident) the pass over P of tick t from its strips,
-        // then predict(t+1) on what it wrote, then the signal
-        rc = launch_on(h, sb, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_a, h->seq_pa, timeouts, 1 << 18);
-        if (!rc && more) rc = launch_on(h, sb, -1, k_tick_wait, dim3(1), dim3(64), 0, (const int*)cnt_s, h->seq_ps + n_front, timeouts, 1 << 18);
-        if (!rc) rc = launch_pass(h, v, o.J, plan, true, false, other);
-        if (rc) return rc;
-        h->sidx ^= 1;
-        h->cidx ^= 1;
-        h->pidx ^= 1;
-        std::swap(h->tk_K, h->tk_K2);     // (tk_K2 / tk_V2: the strips of the tick just enqueued; tk_K / tk_V: where the next one writes)
-        std::swap(h->tk_V, h->tk_V2);
-        plan_prev = plan;
-        prev_J = o.J;
-        if (more) {
-            const View v2 = h->view();   // (s_in: the state after tick t)
-            dim3 grid((h->ld + 255) / 256, 1, h->B), block(256);
-            DISPATCH_T(h, rc = (launch_on(h, sb, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, 0, v2, twist_of(t + 1), (T*)h->P(), 2,
-                                          (T*)nullptr)));
-            if (rc) return rc;
-        }
-        rc = launch_on(h, sb, -1, k_tick_signal, dim3(1), dim3(64), 0, cnt_b);
-        if (rc) return rc;
-        h->seq_pb += 1;
-    }
-    // the handle's stream goes on behind the last pass
-    rc = launch(h, -1, k_tick_wait, dim3(1), dim3(64), (const int*)cnt_b, h->seq_pb, timeouts, 1 << 18);
-    if (rc) return rc;
-    h->host_seen_valid = false;
-    h->last_tick = t_end - 1;
-    return NUSLAM_OK;
-}
-
 void free_batch(nuslam_batch* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->pn_row, h->pn_col, h->pn_state, h->tk_K2, h->tk_V2, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -1323,7 +1163,6 @@ void free_batch(nuslam_batch* h)
     for (auto e : h->ov_events) (void)hipEventDestroy(e);
     if (h->ov_start) (void)hipEventDestroy(h->ov_start);
     if (h->stream2 && h->stream2 != h->stream) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->stream_lo) { (void)hipStreamSynchronize(h->stream_lo); (void)hipStreamDestroy(h->stream_lo); }
     for (int g = 1; g < 4; ++g) {
         if (h->gstream[g]) { (void)hipStreamSynchronize(h->gstream[g]); (void)hipStreamDestroy(h->gstream[g]); }
         if (h->gev[g]) (void)hipEventDestroy(h->gev[g]);
@@ -1878,10 +1717,7 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
     const bool want_overlap = h->overlap < 0 ? (h->B == 1 && h->pass_mode != 0) : h->overlap != 0;
     if (want_overlap && h->ov_ok != 0 && known_trace && t_end - t_begin >= 2 && h->tr_m >= 1 && h->tr_m <= kTickJ && !h->deferred && !h->dense_predict &&
         (h->tick_mode != 0) && (h->tr_bcast ? !h->h_ids.empty() : true)) {
-        rc = kNotConcurrent;
-        if (h->pass_mode == 0 && front_fits(h, false) && (!h->h_ids.empty() || !h->h_ids_pf.empty()))
-            rc = run_pipelined(h, t_begin, t_end, total_landmarks);
-        if (rc == kNotConcurrent) rc = run_overlapped(h, t_begin, t_end, total_landmarks);
+        rc = run_overlapped(h, t_begin, t_end, total_landmarks);
         if (rc != kNotConcurrent) {              // (else: the probe found the streams serialised -> the loop below)
             h->id_log = saved_log;
             return rc;
