@@ -21,6 +21,7 @@ timeout -k 10 200 $B --tick-mode 3 --cpu-seconds 0 > "$OUT/bench_ekf1000_two_lau
 timeout -k 10 200 $B --pass-variant 2 --tick-mode 3 --no-overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_one_stream.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --pass-variant 1 --tick-mode 3 --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_overlapped.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --tick-mode 3 --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_rank_overlapped.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_streamed_overlap.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --per-correction --cpu-seconds 0 > "$OUT/bench_ekf1000_pairs.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --no-pairing --cpu-seconds 0 > "$OUT/bench_ekf1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 > "$OUT/bench_batch.json" 2>> "$OUT/bench.err" || exit 1
