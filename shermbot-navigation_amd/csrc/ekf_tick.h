@@ -74,9 +74,15 @@ struct alignas(16) TickStep {
     int c;                 // first state index of the landmark
     int id;                // resolved id
     double Hc[10], Sinv[4], dz[2], lxy[2];
-    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]; MP[0][7]: the heading after the correction
+    double heading, pad_;          // the wrapped heading after the correction (slam_library.cpp:276)
+    double KV[kTickNU][4];         // K_s(U[p], 0..1), V_s(0..1, U[p]): what the strips need of the index set when they carry their panels in
+                                   // RANK form (rounds the rank-2m pass applies: P -= K_s V_s, two FMAs per entry instead of seven)
+    // ---- the HEAD of an entry ends here (kPlanHeadWords): rank-form strips fetch / stage nothing behind it
+    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]: the exact chain's form of the same
     double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
 };
+constexpr int kPlanHeadWords = 2 + 18 + 2 + kTickNU * 4;      // 8-byte words: the four ints, Hc .. lxy, heading + pad, KV
+static_assert(kPlanHeadWords % 2 == 0, "the head is a whole number of 16-byte pieces");
 
 // What an overlapped run's chain starts from instead of the covariance (FUSED): the strips of the PREVIOUS tick at this
 // tick's index set, dropped into compact arrays by k_tick_panels, the 35 x 35 block k_tick_prep gathered from the
@@ -441,6 +447,8 @@ struct TickPublish {
     int predict;           // != 0: this launch also holds the tick's predict (k_tick_front's middle workgroups)
     int gbase, pbase;      // the values [1] / [2] reach when that has happened
     TwistArg tw;
+    int rank_panels;       // != 0: the strips that follow this chain carry their panels in rank form (the host has proven the round free of
+                           // first sightings and the pass is the rank-2m one): the chain stores the entry's KV rows instead of MP / BR
 };
 constexpr int kPubWords = 4;
 __device__ inline void plan_store(bool publish, double* p, double x)
@@ -482,6 +490,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
     __shared__ int hi[2];
     __shared__ int Ush[NU + 1];
     __shared__ int idsh[kTickJ];
+    __shared__ double KVl[NU][4];                 // the plan entry's KV rows (K_s at the rows U[p], V_s at the columns U[p]) on their way out
     __shared__ int4 dlive[kTickJ + 1];            // the corrections that change P, in order: { marker, first state index, resolved id, init }
     __shared__ int dsum[4];                       // landmarks seen / break flag after the round, first marker with a bounds error, live count
 
@@ -710,9 +719,9 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         const int setP[5] = { 0, 1, 2, cP, cP + 1 };
         TickStep* psP = pl + pv_st;
         // K, M of correction pv at row U[p] and the state there after it (slam_library.cpp:271-275; the heading still raw)
-        auto row_after = [&](int p, double m[5], double& bef, double& aft) {
+        auto row_after = [&](int p, double m[5], double& bef, double& aft, double KP[2]) {
             const int i = Ush[p];
-            double pc[5], Hc[10], Si[4], KP[2];
+            double pc[5], Hc[10], Si[4];
 #pragma unroll
             for (int q = 0; q < 5; ++q) pc[q] = B0[p][spP[q]];          // P(U[p], set[q])
 #pragma unroll
@@ -735,22 +744,39 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 if (lane < NU) {
                     const int p = lane;
                     double m[5], bef, aft;
-                    double sv = row_after(p, m, bef, aft);
+                    double KP[2];
+                    double sv = row_after(p, m, bef, aft, KP);
                     double (*Mn)[8] = MPl[0];
 #pragma unroll
                     for (int q = 0; q < 5; ++q) { Mn[p][q] = m[q]; if (!PUBLISH) psP->MP[p][q] = m[q]; }
                     Mn[p][5] = bef; Mn[p][6] = aft;
                     if (!PUBLISH) {                                     // (the strip workgroups of k_tick_front form the two flags themselves)
                         psP->MP[p][5] = bef; psP->MP[p][6] = aft;
-                        if (p > 0) psP->MP[p][7] = 0.0;
+                        psP->MP[p][7] = 0.0;
                     }
                     if (p == 0) {                                       // the heading row after that correction, wrapped (:276)
                         sv = normalize_angle(sv);
-                        plan_store(PUBLISH, &psP->MP[0][7], sv);
+                        plan_store(PUBLISH, &psP->heading, sv);
                     }
                     SM[scur ^ 1][p] = sv;
+                    // what rank-form strips need of this position: K_s(U[p], :) and V_s(:, U[p]) = H_s P_{s-1}(set_s, U[p]) (hp_entry)
+                    if (!PUBLISH || pub.rank_panels) {
+                        double rsv[5];
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) rsv[q] = B0[spP[q]][p];
+                        const double V0 = hp_entry(hP, rsv, 0), V1 = hp_entry(hP, rsv, 1);
+                        if (PUBLISH) { KVl[p][0] = KP[0]; KVl[p][1] = KP[1]; KVl[p][2] = V0; KVl[p][3] = V1; }
+                        else { psP->KV[p][0] = KP[0]; psP->KV[p][1] = KP[1]; psP->KV[p][2] = V0; psP->KV[p][3] = V1; }
+                    }
                 }
-                if (PUBLISH) {
+                if (PUBLISH && pub.rank_panels) {
+                    // (coalesced, read back from this wave's own LDS copy, as the rows of M below)
+#pragma unroll
+                    for (int k5 = 0; k5 < (NU * 4 + 63) / 64; ++k5) {
+                        const int idx = 64 * k5 + lane;
+                        if (idx < NU * 4) st_agent(&psP->KV[0][0] + idx, (&KVl[0][0])[idx]);
+                    }
+                } else if (PUBLISH) {
                     // the rows of M to the plan, COALESCED: lane l of store k writes word 64 k + l of MP (rows of 8 words), read
                     // back from the LDS copy this wave has just written (a wave's LDS accesses execute in order).  With one row
                     // per lane every store instruction touched 35 different cache lines through the CU's one address path.
@@ -767,7 +793,8 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             if (have && has_cur) {
                 if (lane < NU) {
                     double m[5], bef, aft;
-                    (void)row_after(lane, m, bef, aft);
+                    double KP_[2];
+                    (void)row_after(lane, m, bef, aft, KP_);
                     double (*Mn)[8] = MPl[1];
 #pragma unroll
                     for (int q = 0; q < 5; ++q) Mn[lane][q] = m[q];
@@ -782,10 +809,12 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 // the wait for them in front of the barrier finds them acknowledged
                 const int fresh = B0[posP][posP] > 1.0e9 ? 2 : 0;       // INT_MAX (2.1e9) still on the landmark's diagonal
                 if (PUBLISH) {
+                    if (!pub.rank_panels) {
 #pragma unroll
-                    for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
-                        const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
-                        if (p < NU && q < 5) st_agent(&psP->BR[0][0] + idx, B0[spP[q]][p]);
+                        for (int k5 = 0; k5 < (NU * 8 + 63) / 64; ++k5) {
+                            const int idx = 64 * k5 + lane, p = idx >> 3, q = idx & 7;
+                            if (p < NU && q < 5) st_agent(&psP->BR[0][0] + idx, B0[spP[q]][p]);
+                        }
                     }
                     // the entry's scalars as ONE store instruction, a word per lane: {skip, init}, {c, id}, then Hc[10], Sinv[4],
                     // dz[2], lxy[2], contiguous behind them
@@ -820,7 +849,8 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
                 const int j = lane % 5, p = sp[j];
                 double m[5], bef = 0.0, aft = 0.0, sv;
                 CK(2);
-                if (have) sv = row_after(p, m, bef, aft);
+                double KP_[2];
+                if (have) sv = row_after(p, m, bef, aft, KP_);
                 else sv = S0[p];
                 CK(3);
                 const double th_raw = lane_bcast(sv, 0), x = lane_bcast(sv, 1), y = lane_bcast(sv, 2);
@@ -1074,8 +1104,11 @@ template <typename T, int IDX>
 __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX == 32 ? 2 : 4))) void k_tick_panels(View v, TickObs o, const T* __restrict__ P,
                                                      const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                                      double* __restrict__ Rbuf, double* __restrict__ Vbuf, const int* __restrict__ posmap,
-                                                     double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU)
+                                                     double* __restrict__ KU, double* __restrict__ RU, double* __restrict__ SU, int rank_ok)
 {
+    // rank_ok (the pass is the rank-2m one): a filter whose round holds no first sighting (round_flags: the predicate the pass itself
+    // evaluates) carries its panels in RANK form, P -= K_s V_s -- two FMAs per entry and correction instead of the exact chain's seven,
+    // a quarter of the plan staged (the entries' heads) -- as the pass will apply the round to the covariance
     // Vbuf != null: also V_s = H_s R_s (2 x len, slam_library.cpp:279 written as P - K_s (H_s P)), the second factor of the
     // rank-2m pass (k_tick_rank)
     // posmap != null (overlapped runs): the strips at the NEXT tick's index set are also dropped into the compact arrays
@@ -1094,16 +1127,27 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
 #ifdef NUSLAM_CHAIN_CLOCK
     long long pct = (long long)wall_clock64();
 #endif
-    extern __shared__ double plan_l[];                                  // [J] TickStep
-    {
-        const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
-        Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
-        const int n16 = J * (int)(sizeof(TickStep) / 16);
-        PCK(0, 17);
-        // (4.6 us of this kernel's ~18 at N = 1000: a CU moves a 1 KB wave-load in ~0.25 us here; copying only the rows
-        // that are read -- half of them -- through predicated pieces cost more in address arithmetic than it saved)
-        for (int e = threadIdx.x; e < n16; e += IDX * 8) dst[e] = src[e];
+    extern __shared__ double plan_l[];                                  // [J] TickStep, or [J] heads of kPlanHeadWords words (rank form)
+    bool rankp = false;
+    if (rank_ok) {
+        unsigned am;
+        bool any_init;
+        round_flags(plan + (size_t)b * kTickJ, J, am, any_init);
+        rankp = !any_init;
     }
+    const int ent_words = rankp ? kPlanHeadWords : (int)(sizeof(TickStep) / 8);    // an entry's stride in LDS
+    {
+        Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
+        const int per16 = ent_words / 2, n16 = J * per16;
+        PCK(0, 17);
+        // (4.6 us of this kernel's ~18 at N = 1000 in the exact form: a CU moves a 1 KB wave-load in ~0.25 us here; copying only
+        // the rows that are read -- half of them -- through predicated pieces cost more in address arithmetic than it saved)
+        for (int e = threadIdx.x; e < n16; e += IDX * 8) {
+            const int st = e / per16, w = e - st * per16;
+            dst[e] = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ + st)[w];
+        }
+    }
+    auto entry = [&](int st) { return reinterpret_cast<const TickStep*>(plan_l + (size_t)st * ent_words); };
     PCK(0, 18);
     // this lane's positions p = 4 j + k and the state indices behind them
     int Uk[kQuadRows];
@@ -1120,7 +1164,6 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         }
         Uk[j] = u;
     }
-    const TickStep* pls = reinterpret_cast<const TickStep*>(plan_l);
 
     if (role == 0) {
         // ---- column t of the five-row strips R_s and of the row panel
@@ -1148,10 +1191,10 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         // which corrections change P: one LDS read and a ballot instead of a flag read (and its latency) at the top of
         // every correction; the corrections themselves run WITHOUT a branch around them -- a skipped one computes on its
         // (stale) plan entry and keeps nothing -- so that the sixteen of them are one basic block to the scheduler
-        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[(threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0].skip == 0) & 0xffffu;
+        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && entry((threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0)->skip == 0) & 0xffffu;
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {             // (no break / continue: the loop must unroll, RP is indexed by st)
-            const TickStep* ps = pls + (st < J ? st : 0);
+            const TickStep* ps = entry(st < J ? st : 0);
             PCK(0, 1 + st);
             const bool act = (actmask >> st) & 1u;
             if (IDX == 32 || act) {                       // (IDX == 64, batches: a branch per correction keeps the register count at 110)
@@ -1163,11 +1206,13 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                 const size_t rsp = act ? rstep : 0;
 #pragma unroll
                 for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
-                if (Vbuf) {                                             // (uniform)  V_s(r, t) = sum_q H_s(r, set[q]) R_s(q, t)
+                double V0 = 0.0, V1 = 0.0;                              // V_s(r, t) = sum_q H_s(r, set[q]) R_s(q, t)
+                if (Vbuf || rankp) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
+                if (Vbuf) {                                             // (uniform)
                     double* const vd = act ? vdst : rdump;
                     const size_t vsp = act ? vstep : 0;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) vd[(size_t)(st * 2 + r) * vsp] = hp_entry(ps->Hc, rs, r);
+                    vd[(size_t)(st * 2 + 0) * vsp] = V0;
+                    vd[(size_t)(st * 2 + 1) * vsp] = V1;
                 }
                 if (posmap) {                                           // (uniform)
                     double* const rud = act ? rudst : rudump;
@@ -1181,6 +1226,12 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const int p = 4 * j + k;
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // rows of this and earlier markers are not read again
                     const int pc = on ? p : 0;
+                    if (rankp) {                                        // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
+                        const Pack16<double> kk = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pc][0]);
+                        const double nv = fma(V1, -kk.v[1], fma(V0, -kk.v[0], RP[j]));
+                        RP[j] = (on && act) ? nv : RP[j];
+                        continue;
+                    }
                     const Pack16<double> m01 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][0]);
                     const Pack16<double> m23 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][2]);
                     const Pack16<double> m45 = *reinterpret_cast<const Pack16<double>*>(&ps->MP[pc][4]);
@@ -1209,12 +1260,12 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         __syncthreads();
         PCK(1, 0);
         const int l16 = (threadIdx.x & 63) < kTickJ ? (threadIdx.x & 63) : 0;
-        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && pls[l16].skip == 0) & 0xffffu;
-        const unsigned initmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && (pls[l16].init & 1) != 0) & 0xffffu;
-        const int c_lane = pls[l16].c;                                  // correction (lane & 15)'s landmark index
+        const unsigned actmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && entry(l16)->skip == 0) & 0xffffu;
+        const unsigned initmask = (unsigned)__ballot((int)(threadIdx.x & 63) < J && (entry(l16)->init & 1) != 0) & 0xffffu;
+        const int c_lane = entry(l16)->c;                               // correction (lane & 15)'s landmark index
 #pragma unroll
         for (int st = 0; st < kTickJ; ++st) {
-            const TickStep* ps = pls + (st < J ? st : 0);
+            const TickStep* ps = entry(st < J ? st : 0);
             PCK(1, 1 + st);
             const int c = __builtin_amdgcn_readlane(c_lane, st);
             const bool act = (actmask >> st) & 1u;
@@ -1252,7 +1303,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                 s0 = s0 + acc;                                          // :275
                 // :276 -- the chain formed exactly this sum for the heading and wrapped it (one wave there instead of a
                 // 450-instruction straggler here, sixteen times)
-                if (t == 0) s0 = ps->MP[0][7];
+                if (t == 0) s0 = ps->heading;
                 sv = act ? s0 : sv;
 #pragma unroll
                 for (int j = 0; j < kQuadRows; ++j) {
@@ -1260,6 +1311,12 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const int p = 4 * j + k;
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // columns of this and earlier markers are not read again
                     const int pcx = on ? p : 0;
+                    if (rankp) {                                        // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
+                        const Pack16<double> vv = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pcx][2]);
+                        const double nv = fma(vv.v[1], -K[1], fma(vv.v[0], -K[0], CP[j]));
+                        CP[j] = (on && act) ? nv : CP[j];
+                        continue;
+                    }
                     const Pack16<double> r01 = *reinterpret_cast<const Pack16<double>*>(&ps->BR[pcx][0]);
                     const Pack16<double> r23 = *reinterpret_cast<const Pack16<double>*>(&ps->BR[pcx][2]);
                     const double r4 = ps->BR[pcx][4];
@@ -1369,6 +1426,8 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     // agent-scope load, issued behind the flag's --, one barrier per entry makes the slot whole.  Waits are bounded as before.
     const int* const flagp = pub.flag + kPubWords * b;
     constexpr int kW = (kPlanWords + 255) / 256;
+    const bool rankp = pub.rank_panels != 0;                            // panels in rank form: only the entries' heads are fetched
+    const int ent_words = rankp ? kPlanHeadWords : kPlanWords;
     auto published = [&](int st) {
         const int f = __builtin_amdgcn_readfirstlane(ld_agent(flagp));
         return seq_reached(f, (int)((unsigned)pub.base + (unsigned)(st + 1)));
@@ -1386,14 +1445,14 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
 #pragma unroll
         for (int u = 0; u < kW; ++u) {
             const int w = (int)threadIdx.x + 256 * u;
-            rw[u] = ld_agent(e + (w < kPlanWords ? w : 0));
+            if (u == 0 || !rankp) rw[u] = ld_agent(e + (w < ent_words ? w : 0));       // (the head is < 256 words: one load)
         }
     };
     auto stash = [&](int st) {
 #pragma unroll
         for (int u = 0; u < kW; ++u) {
             const int w = (int)threadIdx.x + 256 * u;
-            if (w < kPlanWords) slot[st & 1][w] = rw[u];
+            if (w < ent_words) slot[st & 1][w] = rw[u];
         }
     };
     if (!failed && J > 0) {
@@ -1432,10 +1491,12 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
 #pragma unroll
                             for (int q = 0; q < 5; ++q) cu_dst[(size_t)(st * 5 + q) * cu_step] = rs[q];
                         }
+                        double V0 = 0.0, V1 = 0.0;
+                        if (Vbuf || rankp) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
                         if (Vbuf) {
                             double* const vd = owner ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : dump;
-#pragma unroll
-                            for (int r = 0; r < 2; ++r) vd[(size_t)(st * 2 + r) * rsp] = hp_entry(ps->Hc, rs, r);
+                            vd[(size_t)(st * 2 + 0) * rsp] = V0;
+                            vd[(size_t)(st * 2 + 1) * rsp] = V1;
                         }
 #pragma unroll
                         for (int j = 0; j < kQuadRows; ++j) {
@@ -1443,6 +1504,11 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const int p = 4 * j + k;
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pc = on ? p : 0;
+                            if (rankp) {                                // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
+                                const double nv = fma(V1, -ps->KV[pc][1], fma(V0, -ps->KV[pc][0], PN[j]));
+                                PN[j] = on ? nv : PN[j];
+                                continue;
+                            }
                             const double m[5] = { ps->MP[pc][0], ps->MP[pc][1], ps->MP[pc][2], ps->MP[pc][3], ps->MP[pc][4] };
                             const int iu = Uk[j];                       // the row of P this entry lives in
                             const double nv = p1_entry<T>(m, rs, PN[j], (iu > 2 && iu < c) ? 1.0 : 0.0, (iu > c + 1) ? 1.0 : 0.0);
@@ -1478,7 +1544,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                         acc = fma(K[0], ps->dz[0], acc);
                         acc = fma(K[1], ps->dz[1], acc);
                         s0 = s0 + acc;                                  // :275
-                        if (t == 0) s0 = ps->MP[0][7];                  // :276, wrapped by the chain
+                        if (t == 0) s0 = ps->heading;                   // :276, wrapped by the chain
                         sv = s0;
 #pragma unroll
                         for (int j = 0; j < kQuadRows; ++j) {
@@ -1486,6 +1552,11 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const int p = 4 * j + k;
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pcx = on ? p : 0;
+                            if (rankp) {                                // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
+                                const double nv = fma(ps->KV[pcx][3], -K[1], fma(ps->KV[pcx][2], -K[0], PN[j]));
+                                PN[j] = on ? nv : PN[j];
+                                continue;
+                            }
                             const double r[5] = { ps->BR[pcx][0], ps->BR[pcx][1], ps->BR[pcx][2], ps->BR[pcx][3], ps->BR[pcx][4] };
                             const double nv = p1_entry<T>(m, r, PN[j], bef, aft);
                             PN[j] = on ? nv : PN[j];

@@ -641,11 +641,11 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
                                        sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
-                                       h->tk_KU, h->tk_RU, h->tk_SU)));
+                                       h->tk_KU, h->tk_RU, h->tk_SU, h->pass_mode == 0 ? 1 : 0)));
     else
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, h->B), dim3(512),
                                        sizeof(TickStep) * (size_t)o.J, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
-                                       h->tk_KU, h->tk_RU, h->tk_SU)));
+                                       h->tk_KU, h->tk_RU, h->tk_SU, h->pass_mode == 0 ? 1 : 0)));
     if (rc) return rc;
     rc = between();
     if (rc) return rc;
@@ -732,13 +732,24 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
     const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);   // (`seen` is cached per TICK, not per round)
+    // With the rank-2m pass the strips carry their panels in rank form in every round without a first sighting.  k_tick_panels decides
+    // that per filter from the round's own flags; the strips that FOLLOW the chain (k_tick_front) cannot -- they start before the
+    // round's flags exist -- and take the form the host can prove: the one-launch form is used only when it can (every filter then
+    // takes the form it would take in any other launch form: same bits).
+    const bool rank_strips = h->pass_mode == 0;
+    const bool front_ok = !rank_strips || !may_init;
+    if (fused_predict && !(front_ok && front_fits(h, true))) {          // (the caller left the predict to the first round's launch)
+        int prc = do_predict(h, *fused_predict);
+        if (prc) return prc;
+        fused_predict = nullptr;
+    }
     for (int i0 = 0; i0 < m; i0 += kTickJ) {
         const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my);
         View v = h->view();
         int rc = NUSLAM_OK;
         const int strip_wgs = (h->ld + 31) / 32;
         const bool with_predict = fused_predict != nullptr && i0 == 0;
-        if (front_fits(h, with_predict)) {
+        if (front_ok && front_fits(h, with_predict)) {
             // chain and strips in ONE launch: the strip workgroups follow the chain entry by entry (k_tick_front); in the
             // tick's first round the predict rides along as workgroups of its own
             double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
@@ -746,6 +757,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             TickPublish pub;
             pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = with_predict ? 1 : 0;
             pub.gbase = (int)(h->seq_gather + 1u); pub.pbase = (int)(h->seq_pred + (unsigned)n_pred);
+            pub.rank_panels = rank_strips ? 1 : 0;
             if (with_predict) pub.tw = *fused_predict;
             else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
@@ -854,7 +866,7 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
             double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
             DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
                                           sizeof(TickStep) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
-                                          (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr)));
+                                          (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, h->pass_mode == 0 ? 1 : 0)));
             if (rc) break;
             // The passes take turns: group g's pass starts when group g-1's (for group 0: the last group's of the previous
             // round) has ended.  Left to themselves the groups run in step -- pass beside pass, strips beside strips -- and
@@ -1044,7 +1056,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
     // on its CU.  The loop that bounds a tick is then chain -> (last entry's strips) -> chain, ~38 us at N = 1000, with the pass
     // over P, the next predict and prep entirely beside it.
     const int n_strip = (h->ld + 31) / 32;
-    const bool streamed = h->front && (long long)(n_strip + 1) * h->B <= h->n_cu;
+    const bool streamed_fits = h->front && (long long)(n_strip + 1) * h->B <= h->n_cu;
     for (int t = t_begin; t < t_end; ++t) {
         TickStep* plan = ((t - t_begin) & 1) ? h->tk_plan2 : h->tk_plan;
         const bool more = t + 1 < t_end;
@@ -1061,6 +1073,9 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
 
         TickPublish pub;
         pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = 0; pub.gbase = pub.pbase = 0;
+        pub.rank_panels = h->pass_mode == 0 ? 1 : 0;
+        // (rank-form strips that follow the chain need the host's proof that the round holds no first sighting: do_tick_rounds)
+        const bool streamed = streamed_fits && (h->pass_mode != 0 || !may_init);
         pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0;
         // ---- chain stream: chain(t): from P for the first tick (behind predict), from the strips of tick t-1 afterwards
         if (t == t_begin) {
