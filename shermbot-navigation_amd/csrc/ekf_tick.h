@@ -44,6 +44,7 @@
 //                  each plan entry (TickPublish: agent-scope stores and loads, no fences) instead of starting when it ends.
 //                  Same arithmetic as k_predict + k_tick_chain + k_tick_panels: same bits.
 #pragma once
+#include <type_traits>
 
 namespace nuslam {
 
@@ -1128,8 +1129,10 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
     long long pct = (long long)wall_clock64();
 #endif
     extern __shared__ double plan_l[];                                  // [J] TickStep, or [J] heads of kPlanHeadWords words (rank form)
-    bool rankp = false;
-    if (rank_ok) {
+    // (rank_ok == 2: the host has proven the round free of first sightings in every filter -- no look at the flags, and the launch
+    // provides LDS for the heads only: twice the workgroups per CU for batches)
+    bool rankp = rank_ok == 2;
+    if (rank_ok == 1) {
         unsigned am;
         bool any_init;
         round_flags(plan + (size_t)b * kTickJ, J, am, any_init);
@@ -1138,13 +1141,19 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
     const int ent_words = rankp ? kPlanHeadWords : (int)(sizeof(TickStep) / 8);    // an entry's stride in LDS
     {
         Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
-        const int per16 = ent_words / 2, n16 = J * per16;
         PCK(0, 17);
         // (4.6 us of this kernel's ~18 at N = 1000 in the exact form: a CU moves a 1 KB wave-load in ~0.25 us here; copying only
         // the rows that are read -- half of them -- through predicated pieces cost more in address arithmetic than it saved)
-        for (int e = threadIdx.x; e < n16; e += IDX * 8) {
-            const int st = e / per16, w = e - st * per16;
-            dst[e] = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ + st)[w];
+        if (rankp) {
+            constexpr int per16 = kPlanHeadWords / 2;                   // (compile-time divisors)
+            for (int e = threadIdx.x; e < J * per16; e += IDX * 8) {
+                const int st = e / per16, w = e % per16;
+                dst[e] = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ + st)[w];
+            }
+        } else {
+            const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
+            const int n16 = J * (int)(sizeof(TickStep) / 16);
+            for (int e = threadIdx.x; e < n16; e += IDX * 8) dst[e] = src[e];
         }
     }
     auto entry = [&](int st) { return reinterpret_cast<const TickStep*>(plan_l + (size_t)st * ent_words); };
@@ -1165,6 +1174,10 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         Uk[j] = u;
     }
 
+    // (the two forms as two instantiations of the same text: a run-time switch inside the sixteen unrolled corrections would cut them
+    // into basic blocks the scheduler cannot move LDS reads across)
+    auto body = [&](auto rk_) {
+    constexpr bool RANKP = decltype(rk_)::value;
     if (role == 0) {
         // ---- column t of the five-row strips R_s and of the row panel
         const bool live = t < L;
@@ -1207,7 +1220,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
 #pragma unroll
                 for (int q = 0; q < 5; ++q) rd[(size_t)(st * 5 + q) * rsp] = rs[q];
                 double V0 = 0.0, V1 = 0.0;                              // V_s(r, t) = sum_q H_s(r, set[q]) R_s(q, t)
-                if (Vbuf || rankp) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
+                if (Vbuf || RANKP) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
                 if (Vbuf) {                                             // (uniform)
                     double* const vd = act ? vdst : rdump;
                     const size_t vsp = act ? vstep : 0;
@@ -1226,7 +1239,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const int p = 4 * j + k;
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // rows of this and earlier markers are not read again
                     const int pc = on ? p : 0;
-                    if (rankp) {                                        // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
+                    if constexpr (RANKP) {                                        // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
                         const Pack16<double> kk = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pc][0]);
                         const double nv = fma(V1, -kk.v[1], fma(V0, -kk.v[0], RP[j]));
                         RP[j] = (on && act) ? nv : RP[j];
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const int p = 4 * j + k;
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // columns of this and earlier markers are not read again
                     const int pcx = on ? p : 0;
-                    if (rankp) {                                        // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
+                    if constexpr (RANKP) {                                        // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
                         const Pack16<double> vv = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pcx][2]);
                         const double nv = fma(vv.v[1], -K[1], fma(vv.v[0], -K[0], CP[j]));
                         CP[j] = (on && act) ? nv : CP[j];
@@ -1329,6 +1342,9 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         if (live && k == 0) v.s_out[(size_t)b * ld + t] = sv;
         if (pm >= 0) SU[(size_t)b * NU + pm] = sv;
     }
+    };
+    if (rankp) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------------ chain and strips in one launch
@@ -1465,6 +1481,8 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         if (threadIdx.x == 0) atomicAdd(timeouts, 1);
     }
 
+    auto loop = [&](auto rk_) {
+    constexpr bool RANKP = decltype(rk_)::value;
 #pragma unroll
     for (int st = 0; st < kTickJ; ++st) {
         if (st < J && !failed) {                                        // (uniform)
@@ -1492,7 +1510,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             for (int q = 0; q < 5; ++q) cu_dst[(size_t)(st * 5 + q) * cu_step] = rs[q];
                         }
                         double V0 = 0.0, V1 = 0.0;
-                        if (Vbuf || rankp) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
+                        if (Vbuf || RANKP) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
                         if (Vbuf) {
                             double* const vd = owner ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : dump;
                             vd[(size_t)(st * 2 + 0) * rsp] = V0;
@@ -1504,7 +1522,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const int p = 4 * j + k;
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pc = on ? p : 0;
-                            if (rankp) {                                // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
+                            if constexpr (RANKP) {                                // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
                                 const double nv = fma(V1, -ps->KV[pc][1], fma(V0, -ps->KV[pc][0], PN[j]));
                                 PN[j] = on ? nv : PN[j];
                                 continue;
@@ -1552,7 +1570,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const int p = 4 * j + k;
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pcx = on ? p : 0;
-                            if (rankp) {                                // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
+                            if constexpr (RANKP) {                                // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
                                 const double nv = fma(ps->KV[pcx][3], -K[1], fma(ps->KV[pcx][2], -K[0], PN[j]));
                                 PN[j] = on ? nv : PN[j];
                                 continue;
@@ -1578,6 +1596,9 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
             }
         }
     }
+    };
+    if (rankp) loop(std::true_type{});
+    else loop(std::false_type{});
     if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
     if (role == 1 && pm >= 0) SU[(size_t)b * NU + pm] = sv;
 }
