@@ -195,7 +195,9 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
 /* nuslam_batch_run on a known-id trace in tick-pipeline mode: enable > 0 lets the serial chain of tick t+1 run on a
  * second stream while the strips and the pass over P of tick t run on the handle's (the host knows the next tick's
  * markers from the resident trace; the streams hand over through device counters, every wait bounded).  Same bits
- * either way.  Before its first overlapped run a handle PROBES whether the two streams really execute side by side (a
+ * either way.  (While a handle's chains and strips fit the chip together, the strips are a launch that FOLLOWS the chain
+ * of the other stream plan entry by plan entry instead of starting when it has ended.)  Before its first overlapped run a
+ * handle PROBES whether the two streams really execute side by side (a
  * profiler's counter pass or a serialising environment makes them take turns, and every hand-off would expire): if not,
  * its runs take the one-stream path -- same bits, no dependency between streams.  enable == 2: test hook, as 1 but the
  * "second stream" is the handle's own, so the probe must find them serialised.  enable < 0 (default): off with the

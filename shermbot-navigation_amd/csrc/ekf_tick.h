@@ -41,8 +41,18 @@
 //   k_tick_front   one filter: predict, chain and strips as ONE launch.  The chain (workgroup 0) gathers its block from the
 //                  covariance before predict and applies predict to it itself (predict_block); the predict workgroups
 //                  rewrite rows / columns 1, 2 of P; the strip workgroups follow the chain entry by entry as it announces
-//                  each plan entry (TickPublish: agent-scope stores and loads, no fences) instead of starting when it ends.
-//                  Same arithmetic as k_predict + k_tick_chain + k_tick_panels: same bits.
+//                  each plan entry (TickPublish: agent-scope stores and loads, no fences) instead of starting when it ends,
+//                  fetching entry s+1 while they apply entry s.  Same arithmetic as k_predict + k_tick_chain + k_tick_panels:
+//                  same bits.  (k_tick_strips / k_tick_chain_pub: the same hand-off between two launches on two streams,
+//                  streamed overlapped runs.)
+//   the chain      ONE barrier-separated phase per correction (it had three): every wave forms for itself what it needs of what
+//                  the previous correction leaves (gain rows, state), the head's wave-uniform work runs on lanes side by side,
+//                  the round's decisions are taken once, one lane per marker (tick_chain).
+//   rank-form strips  in rounds the rank-2m pass applies, the strips carry their panels the way the pass will apply the round to P:
+//                  P(U[p], t) -= K_s(U[p], :) V_s(:, t), two FMAs per entry and correction instead of seven.  The plan entry's
+//                  HEAD holds what that takes (KV rows); k_tick_panels decides the form per filter from the round's flags (or is
+//                  told by the host that every filter qualifies: LDS for the heads only), k_tick_front's strips take the form
+//                  the host can prove -- so a filter's bits do not depend on the launch form it runs in.
 #pragma once
 #include <type_traits>
 

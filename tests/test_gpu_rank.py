@@ -191,3 +191,35 @@ def test_interleaved_groups_are_bit_identical(hip, dtype, variant):
         for k in range(B):
             assert np.array_equal(res[0][0][k][0], r[k][0]) and np.array_equal(res[0][0][k][1], r[k][1]) and res[0][0][k][2] == r[k][2], k
         assert np.array_equal(res[0][1], st)
+
+
+@pytest.mark.parametrize("n,m,dtype,cold", [(40, 16, 0, False), (12, 5, 0, True), (60, 37, 0, False), (30, 16, 1, False)])
+def test_rank_form_strips_same_bits_in_every_launch_form(hip, n, m, dtype, cold):
+    """With the rank-2m pass the strips carry their panels in rank form in rounds without a first sighting (ekf_tick.h).  Which form
+    a filter's round takes must not depend on the launch form it runs in: chain and strips as ONE launch (k_tick_front: the
+    strips take the form the host can prove) against chain, strips, pass as separate launches (k_tick_panels decides from the
+    round's own flags) -- warm, through first sightings (cold: the host cannot prove anything, the one-launch form steps aside),
+    with a skipped marker, a repeated landmark, more markers than a round, fp32 storage: identical state, covariance, seen."""
+    T = 6
+    tr = synth.make_trace(n, T, m, seed=77, straight_every=3, **EXACT_WHEELS)
+    ids = tr.ids.copy()
+    ids[2, 1 % m] = -1
+    if m > 2:
+        ids[4, 2] = ids[4, 0]
+    res = []
+    for mode in (1, 3):                       # 1: one launch (the default), 3: separate launches
+        f = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+        bt = f.as_batch()
+        bt.set_tick_mode(mode)
+        bt.set_pass_variant(hip.PASS_RANK)
+        if not cold:
+            bx, by, wid = synth.warmup_observations(tr.landmarks)
+            bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+            bt.run(0, 1)
+        bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
+        bt.run(0, T)
+        assert bt.status() == (-1, 0)
+        res.append((f.state.copy(), f.cov.copy(), f.seen))
+    assert np.array_equal(res[0][0], res[1][0]), "state"
+    assert np.array_equal(res[0][1], res[1][1]), "covariance"
+    assert res[0][2] == res[1][2]
