@@ -86,14 +86,23 @@ struct alignas(16) TickStep {
     int id;                // resolved id
     double Hc[10], Sinv[4], dz[2], lxy[2];
     double heading, pad_;          // the wrapped heading after the correction (slam_library.cpp:276)
+    // ---- the PREFIX ends here (kPlanPrefixWords).  Strips in the exact chain's form stage / fetch prefix + MP + BR (kPlanExactWords),
+    // strips in rank form prefix + KV, packed as kPlanHeadWords words (plan_kv below)
+    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]
+    double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
     double KV[kTickNU][4];         // K_s(U[p], 0..1), V_s(0..1, U[p]): what the strips need of the index set when they carry their panels in
                                    // RANK form (rounds the rank-2m pass applies: P -= K_s V_s, two FMAs per entry instead of seven)
-    // ---- the HEAD of an entry ends here (kPlanHeadWords): rank-form strips fetch / stage nothing behind it
-    double MP[kTickNU][8];         // M_s(U[p], set_s[0..4]), before-flag, after-flag of row U[p]: the exact chain's form of the same
-    double BR[kTickNU][8];         // BR[p][q] = P_{s-1}(set_s[q], U[p]), q = 0..4
 };
-constexpr int kPlanHeadWords = 2 + 18 + 2 + kTickNU * 4;      // 8-byte words: the four ints, Hc .. lxy, heading + pad, KV
-static_assert(kPlanHeadWords % 2 == 0, "the head is a whole number of 16-byte pieces");
+constexpr int kPlanPrefixWords = 2 + 18 + 2;                             // 8-byte words: the four ints, Hc .. lxy, heading + pad
+constexpr int kPlanExactWords = kPlanPrefixWords + kTickNU * 16;        // ... + MP + BR
+constexpr int kPlanHeadWords = kPlanPrefixWords + kTickNU * 4;          // the packed image of a rank-form entry: prefix, then KV
+static_assert(kPlanPrefixWords % 2 == 0 && kPlanHeadWords % 2 == 0 && kPlanExactWords % 2 == 0, "whole 16-byte pieces");
+static_assert(sizeof(TickStep) == 8 * (kPlanExactWords + kTickNU * 4), "TickStep layout");
+// the KV rows of a PACKED rank-form entry (LDS images: ps points at the prefix, the rows follow it)
+__device__ inline const double (*plan_kv(const TickStep* ps))[4]
+{
+    return reinterpret_cast<const double (*)[4]>(reinterpret_cast<const double*>(ps) + kPlanPrefixWords);
+}
 
 // What an overlapped run's chain starts from instead of the covariance (FUSED): the strips of the PREVIOUS tick at this
 // tick's index set, dropped into compact arrays by k_tick_panels, the 35 x 35 block k_tick_prep gathered from the
@@ -1148,22 +1157,24 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
         round_flags(plan + (size_t)b * kTickJ, J, am, any_init);
         rankp = !any_init;
     }
-    const int ent_words = rankp ? kPlanHeadWords : (int)(sizeof(TickStep) / 8);    // an entry's stride in LDS
+    const int ent_words = rankp ? kPlanHeadWords : kPlanExactWords;             // an entry's stride in LDS
     {
         Pack16<double>* dst = reinterpret_cast<Pack16<double>*>(plan_l);
         PCK(0, 17);
         // (4.6 us of this kernel's ~18 at N = 1000 in the exact form: a CU moves a 1 KB wave-load in ~0.25 us here; copying only
         // the rows that are read -- half of them -- through predicated pieces cost more in address arithmetic than it saved)
         if (rankp) {
-            constexpr int per16 = kPlanHeadWords / 2;                   // (compile-time divisors)
+            constexpr int per16 = kPlanHeadWords / 2;                   // (compile-time divisors): prefix, then the KV rows from the entry's end
+            for (int e = threadIdx.x; e < J * per16; e += IDX * 8) {
+                const int st = e / per16, w = e % per16;
+                dst[e] = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ + st)[w < kPlanPrefixWords / 2 ? w : w + (kPlanExactWords - kPlanPrefixWords) / 2];
+            }
+        } else {
+            constexpr int per16 = kPlanExactWords / 2;                  // prefix + MP + BR: the entry without its KV rows
             for (int e = threadIdx.x; e < J * per16; e += IDX * 8) {
                 const int st = e / per16, w = e % per16;
                 dst[e] = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ + st)[w];
             }
-        } else {
-            const Pack16<double>* src = reinterpret_cast<const Pack16<double>*>(plan + (size_t)b * kTickJ);
-            const int n16 = J * (int)(sizeof(TickStep) / 16);
-            for (int e = threadIdx.x; e < n16; e += IDX * 8) dst[e] = src[e];
         }
     }
     auto entry = [&](int st) { return reinterpret_cast<const TickStep*>(plan_l + (size_t)st * ent_words); };
@@ -1250,7 +1261,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // rows of this and earlier markers are not read again
                     const int pc = on ? p : 0;
                     if constexpr (RANKP) {                                        // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
-                        const Pack16<double> kk = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pc][0]);
+                        const Pack16<double> kk = *reinterpret_cast<const Pack16<double>*>(&plan_kv(ps)[pc][0]);
                         const double nv = fma(V1, -kk.v[1], fma(V0, -kk.v[0], RP[j]));
                         RP[j] = (on && act) ? nv : RP[j];
                         continue;
@@ -1335,7 +1346,7 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
                     const bool on = p < NU && !(p >= 3 && p < pos + 2);  // columns of this and earlier markers are not read again
                     const int pcx = on ? p : 0;
                     if constexpr (RANKP) {                                        // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
-                        const Pack16<double> vv = *reinterpret_cast<const Pack16<double>*>(&ps->KV[pcx][2]);
+                        const Pack16<double> vv = *reinterpret_cast<const Pack16<double>*>(&plan_kv(ps)[pcx][2]);
                         const double nv = fma(vv.v[1], -K[1], fma(vv.v[0], -K[0], CP[j]));
                         CP[j] = (on && act) ? nv : CP[j];
                         continue;
@@ -1453,7 +1464,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
     const int* const flagp = pub.flag + kPubWords * b;
     constexpr int kW = (kPlanWords + 255) / 256;
     const bool rankp = pub.rank_panels != 0;                            // panels in rank form: only the entries' heads are fetched
-    const int ent_words = rankp ? kPlanHeadWords : kPlanWords;
+    const int ent_words = rankp ? kPlanHeadWords : kPlanExactWords;     // (the slot holds the packed image)
     auto published = [&](int st) {
         const int f = __builtin_amdgcn_readfirstlane(ld_agent(flagp));
         return seq_reached(f, (int)((unsigned)pub.base + (unsigned)(st + 1)));
@@ -1471,7 +1482,9 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
 #pragma unroll
         for (int u = 0; u < kW; ++u) {
             const int w = (int)threadIdx.x + 256 * u;
-            if (u == 0 || !rankp) rw[u] = ld_agent(e + (w < ent_words ? w : 0));       // (the head is < 256 words: one load)
+            const int wc = w < ent_words ? w : 0;
+            // (rank form: < 256 words, one load; the KV rows sit at the entry's end)
+            if (u == 0 || !rankp) rw[u] = ld_agent(e + (rankp && wc >= kPlanPrefixWords ? wc + (kPlanExactWords - kPlanPrefixWords) : wc));
         }
     };
     auto stash = [&](int st) {
@@ -1533,7 +1546,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pc = on ? p : 0;
                             if constexpr (RANKP) {                                // (uniform) P(U[p], t) -= K_s(U[p], :) V_s(:, t), the pass's own sum
-                                const double nv = fma(V1, -ps->KV[pc][1], fma(V0, -ps->KV[pc][0], PN[j]));
+                                const double nv = fma(V1, -plan_kv(ps)[pc][1], fma(V0, -plan_kv(ps)[pc][0], PN[j]));
                                 PN[j] = on ? nv : PN[j];
                                 continue;
                             }
@@ -1581,7 +1594,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                             const bool on = p < NU && !(p >= 3 && p < pos + 2);
                             const int pcx = on ? p : 0;
                             if constexpr (RANKP) {                                // (uniform) P(t, U[p]) -= K_s(t, :) V_s(:, U[p])
-                                const double nv = fma(ps->KV[pcx][3], -K[1], fma(ps->KV[pcx][2], -K[0], PN[j]));
+                                const double nv = fma(plan_kv(ps)[pcx][3], -K[1], fma(plan_kv(ps)[pcx][2], -K[0], PN[j]));
                                 PN[j] = on ? nv : PN[j];
                                 continue;
                             }

@@ -641,7 +641,7 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     // the strips' form (ekf_tick.h): exact chain / rank form where the round's flags allow it (1) / rank form, proven by the host (2: LDS
     // for the entries' heads only)
     const int rank_ok = h->pass_mode != 0 ? 0 : (may_init ? 1 : 2);
-    const size_t plan_lds = (rank_ok == 2 ? sizeof(double) * kPlanHeadWords : sizeof(TickStep)) * (size_t)o.J;
+    const size_t plan_lds = sizeof(double) * (rank_ok == 2 ? kPlanHeadWords : kPlanExactWords) * (size_t)o.J;
     if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
                                        plan_lds, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
@@ -869,7 +869,7 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
             double* Rp = (h->pass_mode == 0 && !may_init) ? nullptr : h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
             double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
             DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
-                                          (h->pass_mode == 0 && !may_init ? sizeof(double) * kPlanHeadWords : sizeof(TickStep)) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
+                                          sizeof(double) * (h->pass_mode == 0 && !may_init ? kPlanHeadWords : kPlanExactWords) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
                                           (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, h->pass_mode != 0 ? 0 : (may_init ? 1 : 2))));
             if (rc) break;
             // The passes take turns: group g's pass starts when group g-1's (for group 0: the last group's of the previous

@@ -6,5 +6,5 @@ SRC=gpurun_out/$ROUND
 DST=profiles/$ROUND
 mkdir -p "$DST"
 cp "$SRC"/bench_*.json "$SRC"/*_kernel_stats.csv "$SRC"/*_pmc_hbm_traffic.json "$SRC"/pass_tiles.txt "$DST"/
-[ -f gpurun_out/pytest_gpu.log ] && cp gpurun_out/pytest_gpu.log "$DST"/pytest_gpu.log
+[ -f gpurun_out/$ROUND/pytest_gpu.log ] && cp gpurun_out/$ROUND/pytest_gpu.log "$DST"/pytest_gpu.log
 ls -la "$DST"
