@@ -237,7 +237,7 @@ def api_driven(n, m, tr, bx, by, wid, Q, R):
     if not os.path.exists(exe):
         return {"error": "cpp/tests/api_rate is not built"}
     res = {}
-    ticks = min(tr.ticks, 48)
+    ticks = min(tr.ticks, 256)
     for name, known in (("known_ids", 1), ("unknown_ids", 0)):
         if known:
             q, wx, wy, ww, t2 = float(Q[0, 0]), bx, by, wid, tr

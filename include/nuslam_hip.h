@@ -29,7 +29,11 @@ extern "C" {
 
 /* 2: nuslam_batch_stats is 2*len + 6 doubles (trace(P) at [2*len + 4]); the status enum gained NUSLAM_E_SYNC / _COMM /
  *    _CAPACITY; nuslam_batch_set_pass_variant selects between the rank-2m pass and the exact chain; NUSLAM_K_TICK_RANK */
-#define NUSLAM_HIP_ABI_VERSION 2
+/* 3: nuslam_ekf_predict / _init_landmark / _update of a single filter are RECORDED and applied tick by tick (see "Lazy ticks"
+ *    below; nuslam_ekf_set_lazy); nuslam_ekf_tick_ex; nuslam_batch_inject_fault; a poisoned handle (NUSLAM_E_SYNC) comes back only
+ *    when every filter has been restored.  (Also since 2, not listed then: nuslam_sim_params grew by `fov` and `min_range` --
+ *    a caller compiled against the version-1 struct must be rebuilt.) */
+#define NUSLAM_HIP_ABI_VERSION 3
 
 typedef enum {
     NUSLAM_OK = 0,
@@ -82,6 +86,23 @@ int nuslam_ekf_destroy(nuslam_ekf_t* h);
 /* copy construction / copy assignment of the value type (slam.cpp:157) */
 int nuslam_ekf_clone(const nuslam_ekf_t* h, nuslam_ekf_t** out);
 
+/* Lazy ticks (default ON for handles made by nuslam_ekf_create).  The reference's node drives the filter call by call
+ * (slam.cpp:269 predict, :296 initializeLandmark, :318 update); one pass over the covariance per update() is 2 len^2 w bytes each.
+ * With lazy ticks nuslam_ekf_predict / _init_landmark / _update only RECORD the call; what has been recorded reaches the device as
+ * ONE tick -- the kernels of nuslam_ekf_tick_ex (predict, serial chain and strips in one launch, then one rank-2m pass over the
+ * covariance), bit-identical to that entry on the same inputs -- when the next nuslam_ekf_predict arrives or when anything looks at
+ * the filter: a getter, nuslam_ekf_associate, _clone, _sync, _status, _snapshot, _restore, _tick, any nuslam_batch_* call on the
+ * handle nuslam_ekf_as_batch returned, _destroy (discards).  Consequences a caller can observe:
+ *   - argument errors (a landmark id outside 1..n) are still returned by the call itself; failures detected on the device (a
+ *     singular innovation covariance) are latched as before and surface at the next synchronising call;
+ *   - fewer than four recorded corrections, deferred mode and the dense predict go through the per-call kernels, as with lazy off;
+ *   - an initializeLandmark(z, id) directly followed by update(z, id) with the same z and id (slam.cpp:295-318) becomes that
+ *     correction's first-sighting flag; any other initializeLandmark is applied on its own, in order;
+ *   - nuslam_ekf_get_seen answers from the host's mirror of `seen` while that is exact (predict / initializeLandmark / update
+ *     never move it, slam_library.cpp:188-253) without touching the device.
+ * enable == 0: every call launches its own kernels again (one pass over the covariance per update()). */
+int nuslam_ekf_set_lazy(nuslam_ekf_t* h, int enable);
+
 /* ExtendedKalman::predict(const Twist2D&), slam_library.cpp:65-148.  dy is accepted and ignored, as there. */
 int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy);
 /* The covariance propagation of slam_library.cpp:104 for a caller-supplied dense Jacobian:
@@ -113,12 +134,19 @@ int nuslam_ekf_init_landmark(nuslam_ekf_t* h, double range, double bearing, int 
 int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, const double* mx,
                     const double* my, const int* known_ids, int total_landmarks, int* ids_out);
 
+/* nuslam_ekf_tick with two more degrees of freedom: twist == NULL continues a tick whose predict has already run (no predict, the
+ * cached `seen` of slam.cpp:251 and the break flag stay as they are); polar != 0: a / b hold (range, bearing) pairs -- markers the
+ * caller has already put through cartesian2polar (slam.cpp:286) -- instead of (x, y). */
+int nuslam_ekf_tick_ex(nuslam_ekf_t* h, const double twist_dth_dx[2], int m, const double* a, const double* b, int polar,
+                       const int* known_ids, int total_landmarks, int* ids_out);
+
 /* getStateVector / getCovariance / getSeenLandmarks, slam_library.cpp:284-297.  Synchronise. */
 int nuslam_ekf_len(const nuslam_ekf_t* h, int* len);
 int nuslam_ekf_get_state(nuslam_ekf_t* h, double* out, int len);
 int nuslam_ekf_get_cov(nuslam_ekf_t* h, double* out, int ld);
 int nuslam_ekf_get_seen(nuslam_ekf_t* h, int* seen);
-/* overwrite (state, covariance, seen): checkpoint restore / warm-start fixtures */
+/* overwrite (state, covariance, seen): checkpoint restore / warm-start fixtures.  Waits for every stream of the handle, clears
+ * the filter's strip scratch; a handle poisoned by NUSLAM_E_SYNC accepts ticks again once EVERY one of its filters was restored. */
 int nuslam_ekf_restore(nuslam_ekf_t* h, const double* state, const double* cov, int ld, int seen);
 /* checkpoint: state (len), covariance (column-major, leading dimension ld) and seen in one call -- the reference
  * keeps these three members (slam_library.hpp:26-33); nuslam_ekf_restore takes them back.  Synchronises. */
@@ -306,6 +334,10 @@ int nuslam_batch_profile_read(nuslam_batch_t* h, int kernel, double* total_ms, l
 /* HIP-event stopwatch on the handle's stream (for whole-region timing from a host language) */
 int nuslam_batch_timer_start(nuslam_batch_t* h);
 int nuslam_batch_timer_stop(nuslam_batch_t* h, double* elapsed_ms); /* synchronises */
+/* Fault injection for the recovery paths (tests).  kind 1: count one expired device-side wait, as a hand-off between workgroups
+ * or streams that never arrived would: the next status read reports NUSLAM_E_SYNC and poisons the handle.  kind 2: put NaN into
+ * every filter's gain / factor strips, as a diverged run would leave them. */
+int nuslam_batch_inject_fault(nuslam_batch_t* h, int kind);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,9 @@ struct TickObs {
     int cartesian;
     int log_slot0;         // id_log index of marker 0 of this round, or -1
     int J;                 // markers in this round, 1..kTickJ
+    int forced;            // != 0: the CALLER has taken the decisions of slam.cpp:295-316 (the class driven call by call: every marker
+                           // here is an update() that was really called, MODE_FORCE): no skip / break / `seen` bookkeeping on the device
+    unsigned init_mask;    // forced: bit s = initializeLandmark(z_s, id_s) was called in front of update(z_s, id_s)
 };
 
 // what one correction leaves for k_tick_panels and k_tick_apply (per filter, per marker)
@@ -651,10 +654,12 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         const int st = lane;
         const bool in = st < J;
         const int id_st = in ? idsh[st] : 0;
-        const Decision d0 = resolve(v.n, id_st, seen, cached, brk, 0, MODE_KNOWN, total_landmarks);   // with the round's incoming break flag
+        const int dmode = o.forced ? MODE_FORCE : MODE_KNOWN;          // forced: the caller's own chain ran on the host (lazy class API)
+        const Decision d0 = resolve(v.n, id_st, seen, cached, brk, 0, dmode, total_landmarks);   // with the round's incoming break flag
         const unsigned long long brk_set = __ballot(in && d0.new_brk != 0 && brk == 0);
         const bool brk_here = brk != 0 || (brk_set & ((1ull << st) - 1ull)) != 0ull;
-        const Decision d = resolve(v.n, id_st, seen, cached, brk_here ? 1 : 0, 0, MODE_KNOWN, total_landmarks);
+        Decision d = resolve(v.n, id_st, seen, cached, brk_here ? 1 : 0, 0, dmode, total_landmarks);
+        if (o.forced && !d.skip) d.init = ((o.init_mask >> st) & 1u) != 0u;
         const unsigned long long live = __ballot(in && !d.skip), bad = __ballot(in && d.new_status != 0);
         int smax = in ? d.new_seen : seen;                              // (new_seen = max(seen, id) where the marker counts)
 #pragma unroll
@@ -667,7 +672,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         if (lane == 0) {
             const int nl = __popcll(live);
             dlive[nl] = make_int4(0, 3, 0, 0);
-            dsum[0] = smax; dsum[1] = (brk != 0 || brk_set != 0ull) ? 1 : 0;
+            dsum[0] = smax; dsum[1] = (brk != 0 || brk_set != 0ull) ? 1 : 0;     // (forced: both pass through unchanged)
             dsum[2] = bad ? __ffsll((long long)bad) - 1 : 255; dsum[3] = nl;
         }
     }

@@ -90,6 +90,7 @@ struct nuslam_batch {
     int tick_mode = -1;        // 1: known-id ticks run as chain + panels + one pass over P; 0: one sweep per correction / pair;
                                // -1: whichever is faster for this handle (see tick_pipeline_pays)
     TickStep* tk_plan = nullptr; double* tk_K = nullptr; double* tk_R = nullptr;
+    bool tk_ready = false;     // every buffer of the tick pipeline allocated and initialised (ensure_tick_buffers)
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
     unsigned seq_pub = 0, seq_gather = 0, seq_pred = 0;   // (sequence words: they wrap, the device compares wrapped differences)
     // Interleaved groups (nuslam_batch_set_interleave): a batch's known-id ticks run as G independent groups of filters, each on
@@ -124,7 +125,8 @@ struct nuslam_batch {
     int ov_ok = -1;            // -1: not probed; 1: the two streams were seen running side by side; 0: they were not (a tool or
                                // environment serialises dispatches): overlapped runs then take the one-stream path
     bool poisoned = false;     // a bounded device-side wait expired (NUSLAM_E_SYNC read back): state / covariance are not to be
-                               // trusted; ticks are refused until restore() or a re-initialisation
+                               // trusted; ticks are refused until EVERY filter has been restored (restore()) or re-initialised
+    std::vector<unsigned char> needs_restore;   // [B], while poisoned: filters not restored yet
     hipStream_t stream2 = nullptr;
     TickStep* tk_plan2 = nullptr; int* tk_ctrl4 = nullptr; double* tk_blk = nullptr;
     int* tk_sync = nullptr;                            // {chain, next} completion counters, timeouts
@@ -139,6 +141,22 @@ struct nuslam_batch {
     bool deferred = false;
     double* dU = nullptr; double* dV = nullptr;
     int J = 0;
+    // The class API driven call by call (slam.cpp:269-318): predict() / initializeLandmark() / update() of ONE filter are recorded
+    // here and reach the device as one tick -- k_tick_front + the rank-2m pass, the kernels nuslam_ekf_tick launches -- when the
+    // next predict(), a getter, associateLandmark(), a copy, sync() or anything else that looks at the filter arrives (lazy_flush).
+    struct Lazy {
+        bool on = false;           // nuslam_ekf_create turns it on for single filters (nuslam_ekf_set_lazy)
+        bool has_predict = false;
+        double dth = 0.0, dx = 0.0;
+        std::vector<double> r, phi;            // the recorded update() calls, in order
+        std::vector<int> id;
+        std::vector<unsigned char> init;       // ... and whether initializeLandmark(z, id) with the same z and id came right before
+        bool pend_init = false;                // an initializeLandmark whose update() has not arrived yet
+        double pi_r = 0.0, pi_phi = 0.0;
+        int pi_id = 0;
+        bool busy = false;                     // lazy_flush is running (its own launches must not re-enter it)
+        bool empty() const { return !has_predict && id.empty() && !pend_init; }
+    } lazy;
     bool dense_predict = false;   // do_predict: state-only kernel + the two MFMA products with the staged Jacobian
     bool dense_getA = false;      // ... and the staged Jacobian is getA(tw) itself: I + B, B(1,0), B(2,0) rewritten every predict
     // profiling
@@ -439,7 +457,14 @@ int set_rank_attributes();
 
 int ensure_tick_buffers(nuslam_batch* h)
 {
-    if (h->tk_plan) return NUSLAM_OK;
+    if (h->tk_ready) return NUSLAM_OK;
+    // (a failure partway leaves tk_ready unset: the next call frees what the failed one got and starts over)
+    {
+        void* part[] = { h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub };
+        for (void* p : part)
+            if (p) (void)hipFree(p);
+        h->tk_plan = nullptr; h->tk_K = h->tk_R = h->tk_V = nullptr; h->tk_pub = nullptr;
+    }
     const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply_units<8>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -465,13 +490,18 @@ int ensure_tick_buffers(nuslam_batch* h)
         HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
     }
     h->seq_pub = h->seq_gather = h->seq_pred = 0;
+    h->tk_ready = true;
     return NUSLAM_OK;
 }
 
+// forced_init != null: the markers are update() calls the caller really made (lazy class API): the device takes no decision of
+// slam.cpp:295-316 for them; forced_init[i] != 0: initializeLandmark came in front of marker i
 TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, const int* host_ids, const double* host_mx,
-                      const double* host_my)
+                      const double* host_my, const unsigned char* forced_init = nullptr)
 {
     TickObs o;
+    o.forced = forced_init ? 1 : 0;
+    o.init_mask = 0u;
     o.J = (m - i0) < kTickJ ? (m - i0) : kTickJ;
     o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
     o.ids = host_ids ? nullptr : base.ids;
@@ -483,6 +513,7 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
         o.a0[k] = (in && host_mx) ? host_mx[i0 + k] : (in ? base.a0 : 0.0);
         o.b0[k] = (in && host_my) ? host_my[i0 + k] : (in ? base.b0 : 0.0);
         o.id0[k] = (in && host_ids) ? host_ids[i0 + k] : (in ? base.id0 : 0);
+        if (in && forced_init && forced_init[i0 + k]) o.init_mask |= 1u << k;
     }
     return o;
 }
@@ -732,10 +763,13 @@ bool front_fits(const nuslam_batch* h, bool with_predict)
 
 // fused_predict != null: no predict kernel ran for this tick -- its predict rides in the first round's k_tick_front launch
 int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
-                   const double* host_my, const int* pf_ids, long long pf_stride, const TwistArg* fused_predict = nullptr)
+                   const double* host_my, const int* pf_ids, long long pf_stride, const TwistArg* fused_predict = nullptr,
+                   const unsigned char* forced_init = nullptr)
 {
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
-    const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);   // (`seen` is cached per TICK, not per round)
+    bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);   // (`seen` is cached per TICK, not per round)
+    if (forced_init)                                    // an initializeLandmark the caller made: the round goes through the exact chain
+        for (int i = 0; i < m; ++i) may_init = may_init || forced_init[i] != 0;
     // With the rank-2m pass the strips carry their panels in rank form in every round without a first sighting.  k_tick_panels decides
     // that per filter from the round's own flags; the strips that FOLLOW the chain (k_tick_front) cannot -- they start before the
     // round's flags exist -- and take the form the host can prove: the one-launch form is used only when it can (every filter then
@@ -748,7 +782,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
         fused_predict = nullptr;
     }
     for (int i0 = 0; i0 < m; i0 += kTickJ) {
-        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my);
+        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, host_mx, host_my, forced_init);
         View v = h->view();
         int rc = NUSLAM_OK;
         const int strip_wgs = (h->ld + 31) / 32;
@@ -892,13 +926,22 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
     return NUSLAM_OK;
 }
 
+ObsArg inline_obs(double a, double b, int id, int cartesian)
+{
+    ObsArg o;
+    o.a = nullptr; o.b = nullptr; o.ids = nullptr; o.stride = 0; o.off = 0;
+    o.a0 = a; o.b0 = b; o.id0 = id; o.cartesian = cartesian; o.log_slot = -1;
+    return o;
+}
+
 // One loop body of slam.cpp:250-319 for every filter of the batch.
 int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known, int total,
             const int* host_ids = nullptr, const double* host_mx = nullptr, const double* host_my = nullptr,
-            const int* pf_ids = nullptr, long long pf_stride = 0)
+            const int* pf_ids = nullptr, long long pf_stride = 0, bool no_predict = false)
 {
+    // (no_predict: the markers continue a tick whose predict has already run -- nuslam_ekf_tick_ex without a twist)
     // One filter, known ids, the tick pipeline: no predict kernel -- the predict rides in the first round's launch (k_tick_front)
-    const bool fuse_predict = known && m > 0 && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->predict_bookkeeping &&
+    const bool fuse_predict = !no_predict && known && m > 0 && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->predict_bookkeeping &&
                               front_fits(h, true);
     int rc = NUSLAM_OK;
     if (fuse_predict) {
@@ -909,7 +952,8 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         h->host_seen_valid = false;
         return NUSLAM_OK;
     }
-    rc = do_predict(h, tw);
+    if (no_predict) { if (h->poisoned) return NUSLAM_E_SYNC; h->last_tick = -1; }
+    else rc = do_predict(h, tw);
     if (rc) return rc;
     // Pairing needs every marker of the tick to be a plain correction of an already-initialised landmark, in every
     // filter: then the caller's chain (slam.cpp:295-316) takes the `update` branch for each of them and `seen` does
@@ -978,6 +1022,50 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
             }
     }
     return NUSLAM_OK;
+}
+
+// ---- the class API driven call by call (nuslam_ekf_predict / _init_landmark / _update), recorded and applied as ONE tick
+// What the caller's loop (slam.cpp:269-318) has asked for since the last flush goes to the device: the recorded predict rides in
+// the first round's k_tick_front launch, the recorded update() calls are its corrections in MODE_FORCE (the caller has taken the
+// decisions of slam.cpp:295-316 itself; an initializeLandmark in front of an update is that correction's `init` flag), then the
+// rank-2m pass -- the kernels, and the bits, of nuslam_ekf_tick_ex on the same inputs.  Fewer than four corrections (where the
+// tick pipeline does not pay, tick_pipeline_pays), the deferred and the dense-predict modes take the per-call kernels.
+// A failure drops what was recorded and is returned to the call that triggered the flush.
+int lazy_flush(nuslam_batch* h)
+{
+    nuslam_batch::Lazy& z = h->lazy;
+    if (z.busy || z.empty()) return NUSLAM_OK;
+    z.busy = true;
+    struct Done {
+        nuslam_batch::Lazy& z;
+        ~Done() { z.has_predict = false; z.pend_init = false; z.r.clear(); z.phi.clear(); z.id.clear(); z.init.clear(); z.busy = false; }
+    } done{ z };
+    HIPCHK(hipSetDevice(h->device));
+    const int m = (int)z.id.size();
+    TwistArg tw;
+    tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = z.dth; tw.dx0 = z.dx;
+    int rc = NUSLAM_OK;
+    if (m > 0 && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->B == 1) {
+        if (h->poisoned) return NUSLAM_E_SYNC;
+        h->last_tick = -1;
+        int* saved_log = h->id_log;
+        h->id_log = nullptr;
+        rc = do_tick_rounds(h, inline_obs(0.0, 0.0, 0, 0), m, h->n, z.id.data(), z.r.data(), z.phi.data(), nullptr, 0,
+                            z.has_predict ? &tw : nullptr, z.init.data());
+        h->id_log = saved_log;
+        // (forced corrections do not move `seen`: the host's mirror of it stays what it was)
+    } else {
+        if (z.has_predict) rc = do_predict(h, tw);
+        for (int i = 0; i < m && !rc; ++i) {
+            const ObsArg o = inline_obs(z.r[i], z.phi[i], z.id[i], 0);
+            if (z.init[i]) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+            if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
+            if (!rc) h->touched[z.id[i]] = 1;         // (B == 1: the landmark has been corrected)
+        }
+    }
+    if (!rc && z.pend_init)                             // an initializeLandmark no update() followed
+        rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), inline_obs(z.pi_r, z.pi_phi, z.pi_id, 0), h->state[h->sidx]);
+    return rc;
 }
 
 // nuslam_batch_run with the chains running ahead: the ticks of a resident known-id trace, where the host knows the next
@@ -1237,6 +1325,26 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
     return NUSLAM_OK;
 }
 
+// every stream the handle may have work on (the chain stream of overlapped runs, the group streams of interleaved ones)
+int sync_all_streams(nuslam_batch* h)
+{
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->stream2 && h->stream2 != h->stream) HIPCHK(hipStreamSynchronize(h->stream2));
+    for (int g = 1; g < 4; ++g)
+        if (h->gstream[g]) HIPCHK(hipStreamSynchronize(h->gstream[g]));
+    return NUSLAM_OK;
+}
+// The rank-2m pass reads all 32 factor rows of a filter's K / V strips every round and masks the unused ones by multiplication:
+// what a diverged or abandoned run left there (a NaN) must not survive into the next one (0 * NaN = NaN across all of P).
+int zero_strips(nuslam_batch* h, int b)
+{
+    if (!h->tk_K) return NUSLAM_OK;
+    const size_t per = (size_t)kTickJ * 2 * h->ld;
+    HIPCHK(hipMemsetAsync(h->tk_K + (size_t)b * per, 0, sizeof(double) * per, h->stream));
+    HIPCHK(hipMemsetAsync(h->tk_V + (size_t)b * per, 0, sizeof(double) * per, h->stream));
+    return NUSLAM_OK;
+}
+
 int init_batch(nuslam_batch* h, const double* robot, const double* map, const double Q[9], const double R[4])
 {
     memcpy(h->Q, Q, sizeof(h->Q));
@@ -1267,7 +1375,9 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
     h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
     h->touched.assign((size_t)h->B * (h->n + 1), 0);
+    for (int b = 0; b < h->B; ++b) { int zrc = zero_strips(h, b); if (zrc) return zrc; }
     h->poisoned = false;
+    h->needs_restore.clear();
     h->last_tick = -1;
     return NUSLAM_OK;
 }
@@ -1275,6 +1385,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
 int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
 {
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<int> c((size_t)h->B * C_WORDS);
     HIPCHK(hipMemcpy(c.data(), h->ctrl[h->cidx], sizeof(int) * c.size(), hipMemcpyDeviceToHost));
@@ -1286,15 +1397,24 @@ int read_status(nuslam_batch* h, int clear, int* first_bad, int* status_out)
         HIPCHK(hipMemcpy(&expired, h->tk_sync + 2, sizeof(int), hipMemcpyDeviceToHost));
         if (expired) {
             if (!st) { st = NUSLAM_E_SYNC; bad = 0; }
+            if (!h->poisoned) h->needs_restore.assign((size_t)h->B, 1);
             h->poisoned = true;                    // the run went on from a hand-off that never arrived: nothing after it is valid
             if (clear) HIPCHK(hipMemset(h->tk_sync + 2, 0, sizeof(int)));
         }
     }
+    // a correction was skipped for a singular S: if it was a first sighting the landmark still carries INT_MAX although the
+    // host marked it corrected -- drop the proof for the filter (its rounds go through the checked path until a restore)
+    for (int b = 0; b < h->B; ++b)
+        if (c[(size_t)b * C_WORDS + C_STATUS] == kStatusSingular)
+            for (int id = 0; id <= h->n; ++id) h->touched[(size_t)b * (h->n + 1) + id] = 0;
     if (clear && st) {
         for (int b = 0; b < h->B; ++b) c[(size_t)b * C_WORDS + C_STATUS] = 0;
         HIPCHK(hipMemcpy(h->ctrl[h->cidx], c.data(), sizeof(int) * c.size(), hipMemcpyHostToDevice));
     }
-    if (st == NUSLAM_E_SYNC) h->poisoned = true;     // (the resident association round latches its expired waits in the status word)
+    if (st == NUSLAM_E_SYNC) {                       // (the resident association round latches its expired waits in the status word)
+        if (!h->poisoned) h->needs_restore.assign((size_t)h->B, 1);
+        h->poisoned = true;
+    }
     if (first_bad) *first_bad = bad;
     if (status_out) *status_out = st;
     return NUSLAM_OK;
@@ -1304,6 +1424,7 @@ int get_state(nuslam_batch* h, int b, double* out, int len)
 {
     if (!h || !out || b < 0 || b >= h->B || len < h->L) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->state[h->sidx] + (size_t)b * h->ld, sizeof(double) * h->L, hipMemcpyDeviceToHost));
     return NUSLAM_OK;
@@ -1313,6 +1434,7 @@ int get_cov(nuslam_batch* h, int b, double* out, int ld)
 {
     if (!h || !out || b < 0 || b >= h->B || ld < h->L) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     { int frc = flush_pending(h); if (frc) return frc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     const char* src = (const char*)h->P() + h->esize() * (size_t)b * h->p_stride;
@@ -1332,9 +1454,15 @@ int get_cov(nuslam_batch* h, int b, double* out, int ld)
 int get_seen(nuslam_batch* h, int b, int* seen)
 {
     if (!h || !seen || b < 0 || b >= h->B) return NUSLAM_E_ARG;
+    // The lazy class API: predict / initializeLandmark / update do not move `seen` (slam_library.cpp: only associateLandmark does),
+    // so while the host's mirror is exact the getter answers from it -- no flush, no device round trip (a 4-byte device-to-host
+    // copy costs ~19 us on this box: tools/microbench/roundtrip.hip -- per tick of the caller's loop, slam.cpp:251)
+    if (h->lazy.on && h->B == 1 && h->host_seen_valid) { *seen = h->host_seen[0]; return NUSLAM_OK; }
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(seen, h->ctrl[h->cidx] + (size_t)b * C_WORDS + C_SEEN, sizeof(int), hipMemcpyDeviceToHost));
+    if (h->B == 1) { h->host_seen[0] = *seen; h->host_seen_valid = true; }   // (nothing is in flight: the mirror is exact again)
     return NUSLAM_OK;
 }
 
@@ -1342,7 +1470,12 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
 {
     if (!h || !state || !cov || b < 0 || b >= h->B || ld < h->L || seen < 0 || seen > h->n) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    (void)lazy_flush(h);                                   // (whatever was recorded is about to be overwritten; its errors with it)
     { int frc = flush_pending(h); if (frc) return frc; }
+    // (kernels of a failed overlapped / grouped run may still be in flight on the other streams: nothing of theirs may land
+    // behind what is written here)
+    { int src = sync_all_streams(h); if (src) return src; }
+    { int zrc = zero_strips(h, b); if (zrc) return zrc; }
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<double> s(h->ld, 0.0);
     memcpy(s.data(), state, sizeof(double) * h->L);
@@ -1360,11 +1493,19 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
-    h->poisoned = false;                                   // (a restored filter is a valid one again)
+    if (h->poisoned) {                                     // a restored filter is a valid one again -- the handle once ALL of them are
+        if (h->needs_restore.size() != (size_t)h->B) h->needs_restore.assign((size_t)h->B, 1);
+        h->needs_restore[b] = 0;
+        bool any = false;
+        for (unsigned char nr : h->needs_restore) any = any || nr != 0;
+        if (!any) { h->poisoned = false; h->needs_restore.clear(); }
+    }
     h->last_tick = -1;
     for (int id = 1; id <= h->n; ++id) {                   // which landmarks still carry INT_MAX: the diagonal says
         const size_t c = 3 + 2 * (size_t)(id - 1);
-        h->touched[(size_t)b * (h->n + 1) + id] = cov[c + c * (size_t)ld] < 1.0e9 ? 1 : 0;
+        // (id <= seen: above it the device's chain initialises the landmark at its next known-id marker, slam.cpp:295, and flags
+        // the round as a first sighting whatever the diagonal holds -- the host's proof must say the same)
+        h->touched[(size_t)b * (h->n + 1) + id] = (cov[c + c * (size_t)ld] < 1.0e9 && id <= seen) ? 1 : 0;
     }
     if (h->B == 1) { h->host_seen[0] = seen; h->host_seen_valid = true; }
     else if (h->host_seen_valid) h->host_seen[b] = seen;
@@ -1374,6 +1515,7 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
 // the statistics vector of nuslam_batch_stats into h->stats (device), on the handle's stream
 int launch_stats(nuslam_batch* h)
 {
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     { int frc = flush_pending(h); if (frc) return frc; }
     View v = h->view();
     int rc = NUSLAM_OK;
@@ -1728,6 +1870,7 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
 {
     if (!h || !h->tr_tw || t_begin < 0 || t_end > h->tr_ticks || t_begin > t_end) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     int* saved_log = h->id_log;
     h->id_log = nullptr;  // resident traces do not log resolved ids
     int rc = NUSLAM_OK;
@@ -1859,6 +2002,7 @@ int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     int rc = flush_pending(h);
     if (rc) return rc;
     if (enable && !h->dU) {
@@ -1877,6 +2021,7 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable) { return h ? nuslam_bat
 int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     h->pairing = enable != 0;
     if (enable >= 2) h->group = enable;          // 2: two per pass, 4: four per pass
     return NUSLAM_OK;
@@ -1885,6 +2030,7 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
     if (!h || mode < -1 || mode > 3) return NUSLAM_E_ARG;
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     h->front = mode != 3;                          // 3: as 1 with the chain and the strips as two launches (measurement)
     h->tick_mode = mode == 3 ? 1 : mode;
     return NUSLAM_OK;
@@ -1893,6 +2039,7 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
 {
     if (!h || variant < 0 || (variant > 2 && variant < 10) || variant > 13) return NUSLAM_E_ARG;
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     if (variant >= 10) { h->pass_mode = 0; h->rank_tile = variant - 10; return NUSLAM_OK; }
     h->pass_mode = variant;
     h->rank_tile = 0;
@@ -1920,6 +2067,7 @@ int nuslam_batch_profile(nuslam_batch_t* h, int enable)
 {
     if (!h) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     int rc = drain_profile(h);
     if (rc) return rc;
     for (int k = 0; k < NUSLAM_K_COUNT; ++k) { h->prof_ms[k] = 0; h->prof_n[k] = 0; }
@@ -1931,6 +2079,7 @@ int nuslam_batch_profile_read(nuslam_batch_t* h, int kernel, double* total_ms, l
 {
     if (!h || kernel < 0 || kernel >= NUSLAM_K_COUNT) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     int rc = drain_profile(h);
     if (rc) return rc;
     if (total_ms) *total_ms = h->prof_ms[kernel];
@@ -1944,6 +2093,7 @@ int nuslam_batch_timer_start(nuslam_batch_t* h)
 {
     if (!h) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     HIPCHK(hipEventRecord(h->t0, h->stream));
     return NUSLAM_OK;
 }
@@ -1952,11 +2102,39 @@ int nuslam_batch_timer_stop(nuslam_batch_t* h, double* elapsed_ms)
 {
     if (!h || !elapsed_ms) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
     HIPCHK(hipEventRecord(h->t1, h->stream));
     HIPCHK(hipEventSynchronize(h->t1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->t0, h->t1));
     *elapsed_ms = ms;
+    return NUSLAM_OK;
+}
+
+namespace {
+__global__ void k_fill_nan(double* __restrict__ p, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = __longlong_as_double(0x7ff8000000000000ll);
+}
+} // namespace
+
+int nuslam_batch_inject_fault(nuslam_batch_t* h, int kind)
+{
+    if (!h || kind < 1 || kind > 2) return NUSLAM_E_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    { int lrc = lazy_flush(h); if (lrc) return lrc; }
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    if (kind == 1) {
+        const int one = 1;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->tk_sync + 2, &one, sizeof(int), hipMemcpyHostToDevice));
+        return NUSLAM_OK;
+    }
+    const size_t n = (size_t)h->B * kTickJ * 2 * h->ld;
+    hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->tk_K, n);
+    hipLaunchKernelGGL(k_fill_nan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->tk_V, n);
+    HIPCHK(hipGetLastError());
     return NUSLAM_OK;
 }
 
@@ -1971,8 +2149,17 @@ int nuslam_ekf_create(const double robot[3], const double* map, int n_landmarks,
     nuslam_ekf* h = new (std::nothrow) nuslam_ekf();
     if (!h) { free_batch(core); return NUSLAM_E_NOMEM; }
     h->core = core;
+    core->lazy.on = true;                           // the class API driven call by call reaches the device tick by tick (lazy_flush)
     *out = h;
     return NUSLAM_OK;
+}
+
+int nuslam_ekf_set_lazy(nuslam_ekf_t* h, int enable)
+{
+    if (!h) return NUSLAM_E_ARG;
+    int rc = lazy_flush(h->core);
+    h->core->lazy.on = enable != 0;
+    return rc;
 }
 
 int nuslam_ekf_destroy(nuslam_ekf_t* h)
@@ -1988,6 +2175,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (!src || !out) return NUSLAM_E_ARG;
     nuslam_batch* s = src->core;
     HIPCHK(hipSetDevice(s->device));              // before the flush: it launches on s->stream
+    { int lrc = lazy_flush(s); if (lrc) return lrc; }
     { int frc = flush_pending(s); if (frc) return frc; }
     nuslam_batch* d = nullptr;
     int rc = alloc_batch(1, s->n, s->dtype, s->device, &d);
@@ -1996,6 +2184,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     memcpy(d->R, s->R, sizeof(d->R));
     d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode;
     d->touched = s->touched; d->pass_mode = s->pass_mode; d->rank_tile = s->rank_tile; d->apply_units = s->apply_units;
+    d->lazy.on = s->lazy.on;
     rc = [&]() -> int {
         HIPCHK(hipSetDevice(s->device));
         HIPCHK(hipStreamSynchronize(s->stream));
@@ -2020,6 +2209,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
 int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out)
 {
     if (!h || !out) return NUSLAM_E_ARG;
+    { int lrc = lazy_flush(h->core); if (lrc) return lrc; }
     *out = h->core;
     return NUSLAM_OK;
 }
@@ -2028,26 +2218,40 @@ int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy)
 {
     (void)dy;  // Twist2D::dy is never read by the filter (slam_library.cpp:71-148)
     if (!h) return NUSLAM_E_ARG;
-    HIPCHK(hipSetDevice(h->core->device));
+    nuslam_batch* c = h->core;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->lazy.on) {
+        // the tick recorded so far goes to the device; this predict opens the next one (slam.cpp:269)
+        int lrc = lazy_flush(c);
+        if (lrc) return lrc;
+        if (c->poisoned) return NUSLAM_E_SYNC;
+        c->lazy.has_predict = true; c->lazy.dth = dth; c->lazy.dx = dx;
+        return NUSLAM_OK;
+    }
     TwistArg tw;
     tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
-    return do_predict(h->core, tw);
-}
-
-static ObsArg inline_obs(double a, double b, int id, int cartesian)
-{
-    ObsArg o;
-    o.a = nullptr; o.b = nullptr; o.ids = nullptr; o.stride = 0; o.off = 0;
-    o.a0 = a; o.b0 = b; o.id0 = id; o.cartesian = cartesian; o.log_slot = -1;
-    return o;
+    return do_predict(c, tw);
 }
 
 int nuslam_ekf_update(nuslam_ekf_t* h, double range, double bearing, int id)
 {
     if (!h) return NUSLAM_E_ARG;
-    if (id < 1 || id > h->core->n) return NUSLAM_E_BOUNDS;
-    HIPCHK(hipSetDevice(h->core->device));
-    return do_update(h->core, inline_obs(range, bearing, id, 0), MODE_FORCE, h->core->n);
+    nuslam_batch* c = h->core;
+    if (id < 1 || id > c->n) return NUSLAM_E_BOUNDS;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->lazy.on) {
+        if (c->poisoned) return NUSLAM_E_SYNC;
+        nuslam_batch::Lazy& z = c->lazy;
+        unsigned char init = 0;
+        if (z.pend_init) {
+            if (z.pi_id == id && z.pi_r == range && z.pi_phi == bearing) { init = 1; z.pend_init = false; }   // slam.cpp:295-297, :318
+            else { int lrc = lazy_flush(c); if (lrc) return lrc; }        // an unrelated initializeLandmark: apply it on its own first
+        }
+        z.r.push_back(range); z.phi.push_back(bearing); z.id.push_back(id); z.init.push_back(init);
+        if (z.id.size() >= 4 * (size_t)kTickJ) return lazy_flush(c);      // (bounded record: four rounds)
+        return NUSLAM_OK;
+    }
+    return do_update(c, inline_obs(range, bearing, id, 0), MODE_FORCE, c->n);
 }
 
 int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_out)
@@ -2055,6 +2259,7 @@ int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_
     if (!h || !id_out) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
     HIPCHK(hipSetDevice(c->device));
+    { int lrc = lazy_flush(c); if (lrc) return lrc; }
     int rc = do_associate(c, inline_obs(range, bearing, 0, 0));
     if (!rc) rc = associate_finish(c);
     if (rc) return rc;
@@ -2074,6 +2279,12 @@ int nuslam_ekf_init_landmark(nuslam_ekf_t* h, double range, double bearing, int 
     nuslam_batch* c = h->core;
     if (id < 1 || id > c->n) return NUSLAM_E_BOUNDS;
     HIPCHK(hipSetDevice(c->device));
+    if (c->lazy.on) {
+        nuslam_batch::Lazy& z = c->lazy;
+        if (z.pend_init) { int lrc = lazy_flush(c); if (lrc) return lrc; }   // two in a row: the first one on its own
+        z.pend_init = true; z.pi_r = range; z.pi_phi = bearing; z.pi_id = id;
+        return NUSLAM_OK;
+    }
     View v = c->view();
     return launch(c, -1, k_init_landmark, dim3(1), dim3(1), v, inline_obs(range, bearing, id, 0), c->state[c->sidx]);
 }
@@ -2082,9 +2293,18 @@ int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, co
                     const int* known_ids, int total_landmarks, int* ids_out)
 {
     (void)dy;
+    const double tw[2] = { dth, dx };
+    return nuslam_ekf_tick_ex(h, tw, m, mx, my, 0, known_ids, total_landmarks, ids_out);
+}
+
+int nuslam_ekf_tick_ex(nuslam_ekf_t* h, const double* twist, int m, const double* mx, const double* my, int polar,
+                       const int* known_ids, int total_landmarks, int* ids_out)
+{
     if (!h || m < 0 || (m > 0 && (!mx || !my))) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
     HIPCHK(hipSetDevice(c->device));
+    { int lrc = lazy_flush(c); if (lrc) return lrc; }
+    const double dth = twist ? twist[0] : 0.0, dx = twist ? twist[1] : 0.0;
     int* saved_log = c->id_log;
     if (ids_out && m > 0) {
         int rc = ensure_stage(c, m);
@@ -2097,8 +2317,8 @@ int nuslam_ekf_tick(nuslam_ekf_t* h, double dth, double dx, double dy, int m, co
     TwistArg tw;
     tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
     // one filter: markers and ids travel inside the kernel arguments, nothing is staged
-    ObsArg o = inline_obs(0.0, 0.0, 0, 1);
-    int rc = do_tick(c, tw, o, m, known_ids != nullptr, total_landmarks, known_ids, mx, my);
+    ObsArg o = inline_obs(0.0, 0.0, 0, polar ? 0 : 1);
+    int rc = do_tick(c, tw, o, m, known_ids != nullptr, total_landmarks, known_ids, mx, my, nullptr, 0, twist == nullptr);
     c->id_log = saved_log;
     if (rc) return rc;
     if (ids_out) {
@@ -2135,6 +2355,7 @@ int nuslam_ekf_predict_dense(nuslam_ekf_t* h, const double* F, int ldf)
     nuslam_batch* c = h->core;
     if (!F && !c->f_staged) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(c->device));
+    { int lrc = lazy_flush(c); if (lrc) return lrc; }
     { int frc = flush_pending(c); if (frc) return frc; }
     if (F) {
         const size_t bytes = c->esize() * (size_t)c->p_stride;
@@ -2163,6 +2384,7 @@ int nuslam_ekf_use_dense_predict(nuslam_ekf_t* h, int enable)
 {
     if (!h || enable < 0 || enable > 2) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
+    { int lrc = lazy_flush(c); if (lrc) return lrc; }
     if (enable == 2) {
         // the reference's own predict on the matrix cores: A = I + B resident in HBM, its two non-zeros of B rewritten by
         // every predict from (theta', twist) on the device (k_predict), then P <- A P A^T + Qbar as two dense products

@@ -44,6 +44,9 @@ SYMBOLS = [
     ("nuslam_ekf_associate", C.c_int, [_vp, C.c_double, C.c_double, _ip]),
     ("nuslam_ekf_init_landmark", C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     ("nuslam_ekf_tick", C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_int, _dp, _dp, _ip, C.c_int, _ip]),
+    ("nuslam_ekf_tick_ex", C.c_int, [_vp, _dp, C.c_int, _dp, _dp, C.c_int, _ip, C.c_int, _ip]),
+    ("nuslam_ekf_set_lazy", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_inject_fault", C.c_int, [_vp, C.c_int]),
     ("nuslam_ekf_len", C.c_int, [_vp, _ip]),
     ("nuslam_ekf_get_state", C.c_int, [_vp, _dp, C.c_int]),
     ("nuslam_ekf_get_cov", C.c_int, [_vp, _dp, C.c_int]),
@@ -418,6 +421,10 @@ class Batch:
     def set_pass_variant(self, variant):
         _chk(lib().nuslam_batch_set_pass_variant(self._h, int(variant)), "batch_set_pass_variant")
 
+    def inject_fault(self, kind):
+        """1: one expired device-side wait (-> NUSLAM_E_SYNC at the next status read); 2: NaN into the gain / factor strips."""
+        _chk(lib().nuslam_batch_inject_fault(self._h, int(kind)), "batch_inject_fault")
+
     def profile(self, enable):
         _chk(lib().nuslam_batch_profile(self._h, 1 if enable else 0), "batch_profile")
 
@@ -520,6 +527,32 @@ class EKF:
                                    kid.ctypes.data_as(_ip) if kid is not None else None,
                                    self.n if total_landmarks is None else total_landmarks,
                                    ids_out.ctypes.data_as(_ip) if want_ids else None), "ekf_tick")
+        return ids_out[:m].copy() if want_ids else None
+
+    def set_lazy(self, enable=True):
+        """Lazy ticks (default on): predict / init_landmark / update are recorded and applied as one tick; False: every call
+        launches its own kernels (one pass over the covariance per update -- the reference arithmetic of the bitwise tests)."""
+        _chk(lib().nuslam_ekf_set_lazy(self._h, 1 if enable else 0), "ekf_set_lazy")
+
+    def tick_ex(self, tw, a, b, polar=False, known_ids=None, total_landmarks=None, want_ids=True):
+        """nuslam_ekf_tick_ex: tw None = no predict (the markers continue the current tick); polar: a / b are (range, bearing)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m = a.size
+        assert b.size == m
+        kid = None
+        if known_ids is not None:
+            kid = np.ascontiguousarray(known_ids, dtype=np.int32)
+            assert kid.size == m
+        twp = None
+        if tw is not None:
+            twa = np.ascontiguousarray([tw[0], tw[1]], dtype=np.float64)
+            twp = _p(twa)
+        ids_out = np.zeros(max(m, 1), dtype=np.int32)
+        _chk(lib().nuslam_ekf_tick_ex(self._h, twp, m, _p(a), _p(b), 1 if polar else 0,
+                                      kid.ctypes.data_as(_ip) if kid is not None else None,
+                                      self.n if total_landmarks is None else total_landmarks,
+                                      ids_out.ctypes.data_as(_ip) if want_ids else None), "ekf_tick_ex")
         return ids_out[:m].copy() if want_ids else None
 
     @property

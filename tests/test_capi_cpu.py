@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libnuslam_hip.so does not export " + n
     assert sorted(s[0] for s in nh.SYMBOLS) == names, "python binding table and header disagree"
-    assert nh.lib().nuslam_abi_version() == 2
+    assert nh.lib().nuslam_abi_version() == 3
 
 
 def test_host_helpers_match_oracle():

@@ -1,0 +1,165 @@
+"""Lazy ticks: the class API driven call by call, as nuslam/src/slam.cpp:250-319 drives slam_library::ExtendedKalman
+(getSeenLandmarks -> predict -> per marker [initializeLandmark] / skip / stop -> update), against the explicit one-call
+tick entry (nuslam_ekf_tick_ex) on the same inputs.  The recorded calls reach the device as the SAME kernels
+(k_tick_front + k_tick_rank; the exact chain for rounds with a first sighting), so every comparison here is bitwise:
+state, covariance, `seen`, latched status -- with a getter in mid-tick, a copy in mid-tick, first sightings, a gray-zone
+skip (id < 0: the caller `continue`s, slam.cpp:298-300) and the `id > total` break (:301-316).
+"""
+import numpy as np
+import pytest
+
+from nuslam_hip import synth
+
+pytestmark = pytest.mark.gpu
+Q, R = synth.Q_DEFAULT, synth.R_DEFAULT
+EXACT_WHEELS = dict(dL=0.3125, dR=0.375)
+
+
+def polar(hip, mx, my):
+    z = np.array([hip.cartesian2polar(float(x), float(y)) for x, y in zip(mx, my)])
+    return z[:, 0].copy(), z[:, 1].copy()
+
+
+def drive_like_the_node(f, tw, r, phi, ids, total, seen, peek=None):
+    """slam.cpp:250-319 with known ids, one C-ABI call per call of the node.  peek(i): called in front of marker i.
+    `seen`: the node's seen_landmarks of :251.  With KNOWN ids nothing in the reference ever counts landmarks (only
+    associateLandmark does); the explicit known-id tick counts them on the device (csrc/ekf_update.h resolve(): "what
+    associateLandmark would have counted"), so the caller passes that handle's count -- as cpp/tests/api_rate.cpp, whose
+    map-initialising call is an explicit tick, reads it back from the filter.  Returns the number of update() calls."""
+    updates = 0
+    f.predict(tw[0], tw[1])                                             # :269
+    for i in range(len(ids)):
+        if peek is not None:
+            peek(i)
+        k = int(ids[i])
+        if k > seen:
+            f.init_landmark(r[i], phi[i], k)                            # :295-297
+        elif k < 0:
+            continue                                                    # :298-300
+        elif k > total:
+            break                                                       # :301-316
+        f.update(r[i], phi[i], k)                                       # :318
+        updates += 1
+    return updates
+
+
+def same(a, b):
+    sa, sb = a.state, b.state
+    Pa, Pb = a.cov, b.cov
+    assert np.array_equal(sa, sb), "state differs by %.3e" % np.abs(sa - sb).max()
+    assert np.array_equal(Pa, Pb), "covariance differs by %.3e" % np.abs(Pa - Pb).max()
+    assert a.status() == b.status()
+
+
+@pytest.mark.parametrize("n,m,T", [(40, 16, 8), (60, 37, 4), (1000, 16, 6)])
+def test_lazy_calls_equal_the_explicit_tick_bit_for_bit(hip, n, m, T):
+    """Cold start (tick 0: every landmark a first sighting), then warm ticks; with 37 markers a tick is three rounds."""
+    tr = synth.make_trace(n, T, m, straight_every=3, **EXACT_WHEELS)
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)                     # lazy (the default): call by call
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)                     # one nuslam_ekf_tick_ex per tick
+    for t in range(T):
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+        drive_like_the_node(a, tr.tw[t], r, phi, tr.ids[t], n, b.seen)
+        b.tick_ex(tr.tw[t], r, phi, polar=True, known_ids=tr.ids[t], total_landmarks=n, want_ids=False)
+        if t in (0, 1, T - 1):
+            same(a, b)
+    same(a, b)
+
+
+def test_getter_and_copy_in_mid_tick(hip):
+    """A getter between two update() calls flushes what was recorded so far (predict + the first corrections); the rest of the
+    tick follows without a second predict.  The explicit counterpart is tick_ex on the first markers, then tick_ex without a
+    twist on the others.  A copy taken in mid-tick carries exactly the flushed part."""
+    n, m, T = 100, 16, 5
+    tr = synth.make_wellposed_trace(n, T, m, straight_every=4)
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    # initialise the map through one explicit tick on both (every landmark once)
+    lm = tr.landmarks
+    ids0 = np.arange(1, n + 1, dtype=np.int32)
+    for f in (a, b):
+        f.tick((0.0, 0.0), lm[:, 0], lm[:, 1], known_ids=ids0, want_ids=False)
+    same(a, b)
+    cut = 7
+    copies = {}
+    for t in range(T):
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+
+        def peek(i):
+            if i == cut:
+                copies["state"] = a.state                               # a getter in mid-tick
+                if t == 2:
+                    copies["clone"] = a.clone()                         # ... and a copy
+        drive_like_the_node(a, tr.tw[t], r, phi, tr.ids[t], n, b.seen, peek=peek)
+        b.tick_ex(tr.tw[t], r[:cut], phi[:cut], polar=True, known_ids=tr.ids[t][:cut], total_landmarks=n, want_ids=False)
+        if t == 2:
+            c = copies["clone"]
+            same(c, b)                                                  # the copy holds predict + the first `cut` corrections
+            c.close()
+        assert np.array_equal(copies["state"], b.state)
+        b.tick_ex(None, r[cut:], phi[cut:], polar=True, known_ids=tr.ids[t][cut:], total_landmarks=n, want_ids=False)
+        same(a, b)
+
+
+def test_skip_break_and_first_sighting_inside_a_warm_tick(hip):
+    n, m = 40, 16
+    tr = synth.make_trace(n, 6, m, straight_every=3, **EXACT_WHEELS)
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    broke = False
+    for t in range(6):
+        ids = tr.ids[t].copy()
+        total = n
+        if t == 3:
+            ids[4] = -1                                                 # gray zone: skipped by the caller
+        if t == 4:
+            # capacity below some ids that were seen before: the first such marker stops the loop (slam.cpp:301-316; a NEW
+            # landmark above capacity is initialised and corrected all the same, :295 comes first)
+            total = int(np.sort(ids)[m // 2])
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+        ups = drive_like_the_node(a, tr.tw[t], r, phi, ids, total, b.seen)
+        broke = broke or (t == 4 and ups < m)
+        b.tick_ex(tr.tw[t], r, phi, polar=True, known_ids=ids, total_landmarks=total, want_ids=False)
+        sa, sb = a.state, b.state
+        assert np.array_equal(sa, sb) and np.array_equal(a.cov, b.cov), "tick %d" % t
+    assert broke, "the trace never took the break"
+    # `seen`: the class API leaves it to associateLandmark, as the reference does (slam_library.cpp:188-253)
+    assert a.seen == 0 and b.seen > 0
+
+
+def test_lazy_matches_per_call_kernels_within_rounding_and_few_calls_bitwise(hip):
+    """With lazy off every call launches its own kernels (k_predict, k_update: the oracle's arithmetic bit for bit); lazy on
+    re-associates a tick's corrections as one rank-2m update: rounding-level agreement.  Fewer than four corrections take the
+    per-call kernels either way: bitwise."""
+    n, m, T = 100, 16, 6
+    tr = synth.make_wellposed_trace(n, T, m, straight_every=4)
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    b.set_lazy(False)
+    lm = tr.landmarks
+    ids0 = np.arange(1, n + 1, dtype=np.int32)
+    for f in (a, b):
+        f.tick((0.0, 0.0), lm[:, 0], lm[:, 1], known_ids=ids0, want_ids=False)
+    for t in range(T):
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+        k = 3 if t < 2 else m
+        for f in (a, b):
+            drive_like_the_node(f, tr.tw[t], r[:k], phi[:k], tr.ids[t][:k], n, n)
+        if t < 2:
+            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+    Pa, Pb = a.cov, b.cov
+    assert np.abs(a.state - b.state).max() < 1e-10
+    assert np.abs(Pa - Pb).max() / np.abs(Pb).max() < 1e-12
+
+
+def test_bad_id_is_reported_by_the_call_itself(hip):
+    f = hip.EKF(np.zeros(3), np.zeros(10), Q, R)
+    f.predict(0.01, 0.02)
+    with pytest.raises(hip.NuslamError) as e:
+        f.update(1.0, 0.1, 6)
+    assert e.value.code == hip.E_BOUNDS
+    with pytest.raises(hip.NuslamError) as e:
+        f.init_landmark(1.0, 0.1, 0)
+    assert e.value.code == hip.E_BOUNDS
+    f.sync()
+    assert f.status() == 0

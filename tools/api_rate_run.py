@@ -1,0 +1,17 @@
+"""Run cpp/tests/api_rate (slam_library::ExtendedKalman driven call by call, slam.cpp:250-319) at N = 1000, m = 16 the way
+bench.py's `api_driven` leg does, without the rest of the bench: python tools/api_rate_run.py [ticks]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
+import bench  # noqa: E402
+from nuslam_hip import synth  # noqa: E402
+
+n, m = 1000, 16
+ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+tr = synth.make_wellposed_trace(n, ticks, m, seed=12345)
+bx, by, wid = synth.warmup_observations(tr.landmarks)
+print(json.dumps(bench.api_driven(n, m, tr, bx, by, wid, synth.Q_DEFAULT, synth.R_DEFAULT)))
