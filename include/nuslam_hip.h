@@ -100,7 +100,15 @@ int nuslam_ekf_clone(const nuslam_ekf_t* h, nuslam_ekf_t** out);
  *     correction's first-sighting flag; any other initializeLandmark is applied on its own, in order;
  *   - nuslam_ekf_get_seen answers from the host's mirror of `seen` while that is exact (predict / initializeLandmark / update
  *     never move it, slam_library.cpp:188-253) without touching the device.
- * enable == 0: every call launches its own kernels again (one pass over the covariance per update()). */
+ *   - with nuslam_ekf_associate in the loop (slam.cpp:291) the tick runs as a round SERVED to the host: a resident kernel that takes
+ *     the caller's calls from a mailbox in mapped pinned host memory -- associate(z) is one ~3 us round trip plus the O(len) work of
+ *     the association and of the correction the caller decided on for the previous marker (nuslam_ekf_update / _init_landmark only
+ *     record that decision; it travels with the next call), the pass over the covariance follows once per tick.  Verdicts, ids and
+ *     `seen` are those of the per-call kernels.  The round ends with the next predict / getter / sync, after 16 markers, or by itself
+ *     when no call arrives for 1 ms (it can be re-opened at once: nothing is lost, a correction not yet sent takes the per-call
+ *     kernels); no wave ever waits unboundedly for the host.
+ * enable == 0: every call launches its own kernels again (one pass over the covariance per update()); enable > 1: on, and a served
+ * round closes itself after `enable` microseconds without a call (default 1000; tests use small values to exercise that path). */
 int nuslam_ekf_set_lazy(nuslam_ekf_t* h, int enable);
 
 /* ExtendedKalman::predict(const Twist2D&), slam_library.cpp:65-148.  dy is accepted and ignored, as there. */

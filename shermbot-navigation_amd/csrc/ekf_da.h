@@ -44,6 +44,7 @@ struct DaBuf {
     // resident round only:
     double* AP[2];          // [B][n][16]  what associateLandmark formed for a MATCHING candidate: H (10), psi^-1 (4), z_hat (2)
     long long* keyt;        // [B][kTickJ][nwg]  (tag << 32) | key: the key slot doubles as the workgroup's arrival flag
+    long long* fwd;         // [B][8]  served rounds: the command workgroup 0 took from the host's mailbox, for the other workgroups
 };
 
 // associateLandmark's test of one candidate (slam_library.cpp:209-246) from pb[q][q2] = P(set[q2], set[q]):
@@ -529,6 +530,78 @@ __global__ __launch_bounds__(256) void k_da_step(View v, TickObs o, int st, int 
 //    re-normalisation, on the head wave instead of one lane of the gain wave.
 //  * the replay of rows / columns c, c+1 through corrections 0..s-1 reads its coefficients from LDS one correction ahead.
 constexpr int kStatusSync = 9;      // NUSLAM_E_SYNC
+
+// ------------------------------------------------------------------------------------------------ a round SERVED to the host
+// The class API driven call by call (slam.cpp:279-318): associateLandmark(z) must hand its id back to the caller before the
+// caller decides (initializeLandmark / skip / stop) and calls update() -- one host round trip per marker.  As a kernel launch
+// per call that is ~6.7 us of launch latency plus the kernel on this box (tools/microbench/roundtrip.hip); a RESIDENT round
+// that takes its commands from a mailbox in mapped pinned host memory answers in ~2.9 us plus its own work.  k_da_round<T, true>
+// is that: the same trips as the trace-driven round, but
+//   * at the top of every trip workgroup 0 publishes the verdict of the marker scanned in the previous trip (id, seen,
+//     status: two 8-byte system-scope stores, each carrying the sequence number) and waits for the next command
+//     { the correction the caller has decided on for the previous marker (update(z, id) [+ initializeLandmark]: MODE_FORCE;
+//       none if the caller skipped it), the next marker to scan (associateLandmark(z')), or END };
+//   * workgroup 0 alone reads the mailbox and hands the command on through device memory (agent scope): it is the one arbiter
+//     of "no command came" -- after sv.timeout_ticks it closes the round by itself (PARK: nothing is applied, the trip ends the
+//     round as END would), so a caller that stops calling never leaves waves spinning;  every other wait is bounded too;
+//   * a command is eight 8-byte words read by eight lanes in one instruction and validated by its sequence number and an XOR
+//     checksum instead of a second dependent read over PCIe.
+struct DaServe {
+    const long long* cmd;    // host (mapped, pinned): [0] (seq << 32) | (flags << 24) | id   [1] r  [2] phi  [3] checksum
+                             //                        [4] [5] the correction's own (r, phi) when DA_F_ZOVR   [6] [7] unused
+    long long* ans;          // host (mapped, pinned): [0] (seq << 32) | (unsigned)id   [1] (seq << 32) | kind << 28 | status << 24 | seen
+    int seq0;                // sequence number of the first command of this launch
+    int timeout_ticks;       // 100 MHz ticks workgroup 0 waits for a command before it closes the round by itself
+};
+enum { DA_F_CORR = 1, DA_F_INIT = 2, DA_F_SCAN = 4, DA_F_END = 8, DA_F_ZOVR = 16, DA_F_CLEAR = 32, DA_F_PARK = 64 };
+constexpr long long kDaCmdMagic = 0x5a17c0de5a17c0dell;
+
+__device__ inline long long ld_system(const long long* p)
+{
+    return __hip_atomic_load(const_cast<long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void st_system(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void da_answer(const DaServe& sv, int seq, int id, int seen, int status, int kind)
+{
+    st_system(sv.ans + 1, ((long long)seq << 32) | (long long)(((unsigned)kind << 28) | ((unsigned)(status & 15) << 24) | ((unsigned)seen & 0xffffffu)));
+    st_system(sv.ans + 0, ((long long)seq << 32) | (long long)(unsigned)id);
+}
+// Every thread of the workgroup calls it; returns through cmd_sh[0..5] (LDS): word 0 (flags, id), r, phi, -, the correction's
+// own (r, phi).  Wave 0 does the waiting; the barrier at the end publishes cmd_sh.
+__device__ inline void da_wait_cmd(const DaServe& sv, int seq, int wg, long long* fwd, long long* cmd_sh, int* expired_sh)
+{
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const long long t0 = (long long)wall_clock64();
+        // (the other workgroups give workgroup 0 its whole timeout plus the time a healthy chip needs to hand a command on)
+        const long long limit = wg == 0 ? (long long)sv.timeout_ticks : (long long)sv.timeout_ticks + 200000ll;
+        long long w = 0;
+        int ok = 0, expired = 0;
+        for (;;) {
+            if (lane < 8) w = wg == 0 ? ld_system(sv.cmd + lane) : ld_agent(fwd + lane);
+            long long x = (lane < 6 && lane != 3) ? w : 0ll;
+            x ^= __shfl_xor(x, 1, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 4, 64);
+            const long long w0 = __shfl(w, 0, 64), w3 = __shfl(w, 3, 64), xs = __shfl(x, 0, 64);
+            ok = (int)(w0 >> 32) == seq && (xs ^ kDaCmdMagic) == w3;
+            if (ok) break;
+            if ((long long)wall_clock64() - t0 > limit) { expired = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (expired) {
+            // nothing came: the round ends here, nothing applied (workgroup 0 tells the host that command `seq` was NOT taken)
+            const long long w0 = ((long long)seq << 32) | ((long long)(DA_F_PARK | DA_F_END) << 24);
+            w = lane == 0 ? w0 : (lane == 3 ? (w0 ^ kDaCmdMagic) : 0ll);
+        }
+        if (wg == 0) {
+            if (lane < 8) st_agent(fwd + lane, w);
+            if (expired && lane == 0) da_answer(sv, seq, 0, 0, 0, 1);
+        }
+        if (lane < 6) cmd_sh[lane] = w;
+        if (lane == 0) *expired_sh = (expired && wg != 0) ? 1 : 0;     // (a follower that never heard from workgroup 0: NUSLAM_E_SYNC)
+    }
+    __syncthreads();
+}
+
 constexpr int kDaRoundLds = (kTickJ * 5 + kTickJ * 2 + kTickJ * 5) * kDaSlots * (int)sizeof(double);
 
 // (st_agent / ld_agent: ekf_tick.h)
@@ -539,10 +612,10 @@ __device__ long long g_da_clock[4][16];       // debug builds (make daclock): pe
 #else
 #define DCK(k) do { } while (0)
 #endif
-template <typename T>
+template <typename T, bool SERVED>
 __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_landmarks, const T* __restrict__ P, DaBuf d,
                                                   TickStep* __restrict__ plan, double* __restrict__ Kbuf,
-                                                  double* __restrict__ Rbuf, double* __restrict__ Vbuf, int round_tag)
+                                                  double* __restrict__ Rbuf, double* __restrict__ Vbuf, int round_tag, DaServe srv)
 {
     const int b = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -572,6 +645,8 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
     __shared__ double Zl[2][kTickJ];
     __shared__ double candZ[kDaLm][2];
     __shared__ int meet_sh[2];                // the reduced key of the next marker, whether every workgroup arrived
+    __shared__ long long cmd_sh[6];           // SERVED: the command of this trip
+    __shared__ int cmd_expired_sh;
 
     // ---- prologue (k_da_begin): the tracked entries out of the covariance after predict
     double e3[3] = { 0.0, 0.0, 0.0 }, sv = 0.0;            // wave 0: TR[.][t]; wave 1: TC[.][t] and the state entry
@@ -606,7 +681,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 nTD[lane][e] = val;
             }
         }
-    } else if (lane < kTickJ) {
+    } else if (!SERVED && lane < kTickJ) {
         double a = 0.0, bb = 0.0;
         if (lane < J) {
             a = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
@@ -628,9 +703,40 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
     }
     unsigned live = 0;                                     // corrections so far that changed P
     int key = kNoKey;                                      // the reduced key of marker st (from the meet)
+    int scanned = 0, match_id = 0;                         // SERVED: the previous trip scanned a marker; the landmark it matched
+    if (SERVED) brk = 0;                                   // (the caller's own chain decides about the break, slam.cpp:301-316)
 
-    for (int st = -1; st < J; ++st) {
-        const bool last = st + 1 == J;
+    for (int st = -1; st < (SERVED ? kTickJ : J); ++st) {
+        bool last = st + 1 == J;
+        int f_flags = 0, f_id = 0;                         // SERVED: this trip's command
+        if (SERVED) {
+            // the verdict of the marker scanned in the previous trip (slam_library.cpp:238-252) goes to the caller ...
+            int ans_id = 0;
+            match_id = 0;                                  // (what a scan formed for its match is good for the very next correction only)
+            if (scanned) {
+                const Assoc a = decode_association(n, seen, 0, status, key);
+                ans_id = a.id; seen = a.new_seen; status = a.new_status;
+                if (key != kNoKey && (key & 3) == 0) match_id = key >> 2;
+            }
+            const int seq = srv.seq0 + st + 1;
+            if (st >= 0 && wg == 0 && tid == 0) da_answer(srv, seq - 1, ans_id, seen, status, 0);
+            // ... and the caller's next call comes back
+            da_wait_cmd(srv, seq, wg, d.fwd + 8 * (size_t)b, cmd_sh, &cmd_expired_sh);
+            const long long w0 = cmd_sh[0];
+            f_flags = (int)((w0 >> 24) & 0xff);
+            f_id = (int)(w0 & 0xffffffll);
+            if (cmd_expired_sh && status == 0) status = kStatusSync;
+            if (f_flags & DA_F_CLEAR) status = 0;
+            if (st < 0) f_flags &= ~DA_F_CORR;             // (the first command of a round can only scan)
+            const bool scan = (f_flags & DA_F_SCAN) != 0 && st + 1 < kTickJ;
+            last = !scan && ((f_flags & DA_F_END) != 0 || st + 1 >= kTickJ);
+            if (tid == 0) {
+                if (scan) { Zl[0][st + 1] = __longlong_as_double(cmd_sh[1]); Zl[1][st + 1] = __longlong_as_double(cmd_sh[2]); }
+                if (st >= 0 && (f_flags & DA_F_ZOVR)) { Zl[0][st] = __longlong_as_double(cmd_sh[4]); Zl[1][st] = __longlong_as_double(cmd_sh[5]); }
+            }
+            scanned = scan ? 1 : 0;
+            __syncthreads();
+        }
         bool nocorr = true;
         int c = 3;
         double m5[5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }, bef = 0.0, aft = 0.0;  // wave 1: M_s(t, set_s)
@@ -642,16 +748,26 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
             const double* sc = d.DS[par] + (size_t)b * ld;
             DCK(0);
             // ---- the decision, by every thread: associateLandmark's verdict, then slam.cpp:295-316
-            int id_raw, seen_now, status_now;
-            {
+            Decision dd;
+            if (SERVED) {
+                // the caller has decided (slam.cpp:295-316 ran on the host): update(z, id) was called, or it was not
+                dd.id = f_id; dd.new_seen = seen; dd.new_brk = brk; dd.new_status = status;
+                dd.skip = (f_flags & DA_F_CORR) == 0;
+                dd.init = !dd.skip && (f_flags & DA_F_INIT) != 0;
+                if (!dd.skip && (f_id < 1 || f_id > n)) { dd.skip = true; dd.init = false; if (dd.new_status == 0) dd.new_status = kStatusBounds; }
+                dd.c = dd.skip ? 3 : 3 + 2 * (f_id - 1);
+            } else {
+                int id_raw, seen_now, status_now;
                 const Assoc a = decode_association(n, seen, brk, status, key);
                 id_raw = a.id; seen_now = a.new_seen; status_now = a.new_status;
                 if (o.ids != nullptr && o.ids[b * o.stride + o.off + st] < 0) { id_raw = -1; seen_now = seen; status_now = status; }
+                dd = resolve(n, id_raw, seen_now, cached, brk, status_now, MODE_DA, total_landmarks);
             }
-            const Decision dd = resolve(n, id_raw, seen_now, cached, brk, status_now, MODE_DA, total_landmarks);
             c = dd.c;
             const int setv[5] = { 0, 1, 2, c, c + 1 };
-            const bool matched = !dd.skip && !dd.init;     // update() of a landmark associateLandmark has just examined
+            // update() of a landmark associateLandmark has just examined (SERVED: of the very landmark it matched, with the marker it
+            // was given)
+            const bool matched = !dd.skip && !dd.init && (!SERVED || (f_id == match_id && (f_flags & DA_F_ZOVR) == 0));
             DCK(1);
 
             // ---- loads that depend on the landmark
@@ -769,8 +885,10 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     dz0 = r - lane_bcast(val, 54);                      // :272, bearing innovation not wrapped
                     dz1 = phi - lane_bcast(val, 55);
                 } else if (!skip0) {
-                    lx = x + r * cos(phi + th);                         // initializeLandmark, slam_library.cpp:255-261
-                    ly = y + r * sin(phi + th);
+                    if (!SERVED || dd.init) {                           // (trace-driven: not matched means a first sighting)
+                        lx = x + r * cos(phi + th);                     // initializeLandmark, slam_library.cpp:255-261
+                        ly = y + r * sin(phi + th);
+                    }
                     double pb[5][5], S[4];
 #pragma unroll
                     for (int a = 0; a < 5; ++a)
@@ -904,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
         // everything a candidate's psi needs being then in THIS wave's hands -- the next marker's candidates up to
         // psi^-1 (H from the new state, psi = H P H^T + R);  wave 3: their z_hat (three atan2, two sincos: the long pole
         // of this phase);  waves 0, 2: the stores of the correction.
-        const bool cand = !last && !(brk || seen == 0 || seen >= n) && lane < kDaLm && wg * kDaLm + lane + 1 <= seen;
+        const bool cand = !last && (!SERVED || scanned) && !(brk || seen == 0 || seen >= n) && lane < kDaLm && wg * kDaLm + lane + 1 <= seen;
         const int s0 = 3 + 2 * (lane < kDaLm ? lane : 0);               // slot of the candidate's first index
         double cH[10], cPi[4];                                          // wave 1: the candidate's H and psi^-1
         int csing = 0;
@@ -988,7 +1106,11 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
             }
         }
         DCK(6);
-        if (last) break;
+        if (last) {
+            // (SERVED: the END command has been carried out -- a round that parked has said so already)
+            if (SERVED && wg == 0 && tid == 0 && (f_flags & DA_F_PARK) == 0) da_answer(srv, srv.seq0 + st + 1, 0, seen, status, 0);
+            break;
+        }
         __syncthreads();
         DCK(7);
 

@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -157,6 +158,23 @@ struct nuslam_batch {
         bool busy = false;                     // lazy_flush is running (its own launches must not re-enter it)
         bool empty() const { return !has_predict && id.empty() && !pend_init; }
     } lazy;
+    // ... with associateLandmark() in the loop (slam.cpp:291): a resident round kernel that takes the caller's calls from a mailbox in
+    // mapped pinned host memory (k_da_round<T, true>, csrc/ekf_da.h "a round SERVED to the host")
+    struct Serve {
+        long long* mail = nullptr;             // [0..7] the command, [8..9] the answer (two cache lines)
+        int seq = 0;                           // sequence number of the last command sent
+        bool open = false;                     // a served round is resident on the device
+        int trips = 0;                         // commands of this round the device has carried out
+        bool any_init = false;                 // one of its corrections was a first sighting (the caller initialised the landmark)
+        bool pend = false;                     // the correction the caller has decided on for the last marker: sent with the next command
+        int p_id = 0; bool p_init = false; double p_r = 0.0, p_phi = 0.0;
+        bool z_valid = false; double z_r = 0.0, z_phi = 0.0;    // the marker the device scanned last (its correction's default z)
+        bool clear_status = false;             // the latched status was returned to the caller: the next command clears it
+        int timeout_us = 1000;                 // the device closes a round by itself when no command comes for this long
+        bool used = false;                     // associateLandmark was called since the last predict: the caller's loop is slam.cpp's, and
+                                               // the next predict() opens the next served round at once (predict kernel and round kernel
+                                               // queue up behind the pass over P instead of waiting for the first associateLandmark)
+    } srv;
     bool dense_predict = false;   // do_predict: state-only kernel + the two MFMA products with the staged Jacobian
     bool dense_getA = false;      // ... and the staged Jacobian is getA(tw) itself: I + B, B(1,0), B(2,0) rewritten every predict
     // profiling
@@ -694,7 +712,7 @@ int ensure_da_buffers(nuslam_batch* h)
     const int nwg = (h->ld - 3 + kDaOwn - 1) / kDaOwn > 0 ? (h->ld - 3 + kDaOwn - 1) / kDaOwn : 1;
     // one allocation: 2 x (TR, TC) [B][3][ld], 2 x TD [B][4][n], 2 x DS [B][ld], Z [B][2][kTickJ]; then the int arrays
     // ... AP 2 x [B][n][16], keyt [B][kTickJ][nwg] (8-byte words)
-    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ + 2 * B * n * 16 + B * kTickJ * (size_t)nwg;
+    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ + 2 * B * n * 16 + B * kTickJ * (size_t)nwg + 8 * B;
     const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg;
     HIPCHK(hipMalloc(&h->da_mem, nd * sizeof(double) + ni * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->da_mem, 0, nd * sizeof(double) + ni * sizeof(int), h->stream));
@@ -706,12 +724,15 @@ int ensure_da_buffers(nuslam_batch* h)
     h->da.Z = p; p += B * 2 * kTickJ;
     for (int k = 0; k < 2; ++k) { h->da.AP[k] = p; p += B * n * 16; }
     h->da.keyt = (long long*)p; p += B * kTickJ * (size_t)nwg;
+    h->da.fwd = (long long*)p; p += 8 * B;
     int* q = (int*)p;
     for (int k = 0; k < 2; ++k) { h->da.DC[k] = q; q += B * C_WORDS; }
     h->da.keyp = q;
     h->da.nwg = nwg;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_da_round<float, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kDaRoundLds));
     return NUSLAM_OK;
 }
 
@@ -730,8 +751,8 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
         // all workgroups of the resident kernel must be on the chip together (they wait for each other): one per CU at most
         const bool resident = h->tick_mode != 2 && (long long)h->da.nwg * h->B <= h->n_cu;
         if (resident) {
-            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T>, grid, block, (size_t)kDaRoundLds, v, o, total,
-                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, vbuf, (int)h->da_round_tag)));
+            DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T, false>, grid, block, (size_t)kDaRoundLds, v, o, total,
+                                           (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, vbuf, (int)h->da_round_tag, DaServe{})));
             if (rc) return rc;
             h->da_round_tag += kTickJ + 1;
         } else {
@@ -1024,6 +1045,208 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     return NUSLAM_OK;
 }
 
+// ---- the served round (unknown association driven call by call): host side of csrc/ekf_da.h "a round SERVED to the host"
+bool serve_usable(const nuslam_batch* h)
+{
+    return h->lazy.on && h->B == 1 && h->n >= 1 && h->tick_mode != 0 && h->tick_mode != 2 && !h->deferred && !h->dense_predict &&
+           (h->ld - 3 + kDaOwn - 1) / kDaOwn <= h->n_cu;
+}
+int serve_open(nuslam_batch* h)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    { int erc = ensure_da_buffers(h); if (erc) return erc; }
+    if (!sv.mail) {
+        HIPCHK(hipHostMalloc((void**)&sv.mail, sizeof(long long) * 32, hipHostMallocMapped));
+        for (int i = 0; i < 32; ++i) sv.mail[i] = 0;
+    }
+    if (h->poisoned) return NUSLAM_E_SYNC;
+    h->last_tick = -1;
+    TickObs o = make_tick_obs(h, inline_obs(0.0, 0.0, 0, 0), 0, kTickJ, nullptr, nullptr, nullptr);
+    o.log_slot0 = -1;
+    DaServe ds;
+    ds.cmd = sv.mail; ds.ans = sv.mail + 8; ds.seq0 = sv.seq + 1; ds.timeout_ticks = sv.timeout_us * 100;
+    const View v = h->view();
+    double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_DA_STEP, k_da_round<T, true>, dim3(h->da.nwg, 1), dim3(256), (size_t)kDaRoundLds, v, o, h->n,
+                                   (const T*)h->P(), h->da, h->tk_plan, h->tk_K, h->tk_R, vbuf, (int)h->da_round_tag, ds)));
+    if (rc) return rc;
+    h->da_round_tag += kTickJ + 1;
+    sv.open = true; sv.trips = 0; sv.any_init = false; sv.z_valid = false;
+    return NUSLAM_OK;
+}
+void serve_send(nuslam_batch* h, int flags, int id, double r, double phi, double cr, double cphi)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    if (sv.clear_status) { flags |= DA_F_CLEAR; sv.clear_status = false; }
+    volatile long long* m = sv.mail;
+    long long w1, w2, w4, w5;
+    memcpy(&w1, &r, 8); memcpy(&w2, &phi, 8); memcpy(&w4, &cr, 8); memcpy(&w5, &cphi, 8);
+    sv.seq += 1;
+    const long long w0 = ((long long)sv.seq << 32) | ((long long)(flags & 0xff) << 24) | (long long)(id & 0xffffff);
+    m[1] = w1; m[2] = w2; m[4] = w4; m[5] = w5;
+    m[3] = w0 ^ w1 ^ w2 ^ w4 ^ w5 ^ kDaCmdMagic;
+    __atomic_store_n((long long*)&m[0], w0, __ATOMIC_RELEASE);
+}
+// the device's answer to command sv.seq: 0 = carried out (id / seen / status filled in), 1 = the round had parked: the command was
+// NOT taken; < 0: nothing came back (NUSLAM_E_SYNC)
+int serve_wait(nuslam_batch* h, int* id, int* seen, int* status)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    volatile long long* a = sv.mail + 8;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        const long long a0 = a[0], a1 = a[1];
+        if ((int)(a0 >> 32) == sv.seq && (int)(a1 >> 32) == sv.seq) {
+            const unsigned lo = (unsigned)(a1 & 0xffffffffll);
+            if (id) *id = (int)(a0 & 0xffffffffll);
+            if (seen) *seen = (int)(lo & 0xffffffu);
+            if (status) *status = (int)((lo >> 24) & 15u);
+            return (int)(lo >> 28) & 1;
+        }
+        __builtin_ia32_pause();
+        if ((spin & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return -1;
+    }
+}
+// the round is over on the device (END carried out, or parked): the ONE pass over P for its `slots` corrections
+int serve_close(nuslam_batch* h, int slots)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    sv.open = false; sv.z_valid = false;
+    if (slots <= 0) return NUSLAM_OK;                       // (the round ended before its first correction slot: nothing was written)
+    const View v = h->view();
+    int rc = launch_pass(h, v, slots, h->tk_plan, false, sv.any_init, whole(h));
+    if (rc) return rc;
+    h->sidx ^= 1;
+    h->cidx ^= 1;
+    h->pidx ^= 1;
+    if (sv.any_init) for (auto& t : h->touched) t = 0;     // (which landmarks: not tracked for served rounds -- drop the proof)
+    return NUSLAM_OK;
+}
+int serve_poison(nuslam_batch* h)
+{
+    if (!h->poisoned) h->needs_restore.assign((size_t)h->B, 1);
+    h->poisoned = true;
+    h->srv.open = false;
+    return NUSLAM_E_SYNC;
+}
+// One command and its answer.  parked_out: the device had closed the round by itself before the command arrived (nothing of it was
+// applied; the round has been closed here as well).
+int serve_roundtrip(nuslam_batch* h, int flags, int id, double r, double phi, double cr, double cphi, int* id_out, int* status_out,
+                    bool* parked_out)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    serve_send(h, flags, id, r, phi, cr, cphi);
+    int seen = 0, st = 0, rid = 0;
+    const int k = serve_wait(h, &rid, &seen, &st);
+    if (k < 0) return serve_poison(h);
+    *parked_out = k == 1;
+    if (k == 1) return serve_close(h, sv.trips);           // trips executed incl. the parking one = trips + 1; slots = that - 1
+    sv.trips += 1;
+    if (flags & DA_F_SCAN) { h->host_seen[0] = seen; h->host_seen_valid = true; }
+    if (id_out) *id_out = rid;
+    if (status_out) *status_out = st;
+    if (flags & DA_F_END) return serve_close(h, sv.trips - 1);
+    return NUSLAM_OK;
+}
+// flags + payload of the correction the caller has decided on (none: 0)
+int serve_pending_flags(nuslam_batch* h, double* cr, double* cphi)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    *cr = *cphi = 0.0;
+    if (!sv.pend) return 0;
+    int f = DA_F_CORR | (sv.p_init ? DA_F_INIT : 0);
+    if (!(sv.z_valid && sv.z_r == sv.p_r && sv.z_phi == sv.p_phi)) { f |= DA_F_ZOVR; *cr = sv.p_r; *cphi = sv.p_phi; }
+    if (sv.p_init) sv.any_init = true;
+    return f;
+}
+int lazy_flush(nuslam_batch* h);
+// the served round's end: the correction still pending goes with the END command
+int serve_end(nuslam_batch* h)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    if (!sv.open) return NUSLAM_OK;
+    double cr, cphi;
+    const int f = serve_pending_flags(h, &cr, &cphi);
+    bool parked = false;
+    int st = 0;
+    int rc = serve_roundtrip(h, f | DA_F_END, sv.pend ? sv.p_id : 0, 0.0, 0.0, cr, cphi, nullptr, &st, &parked);
+    if (rc) return rc;
+    if (parked && sv.pend) {
+        // the device had closed the round before this arrived: the correction goes through the per-call kernels
+        const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
+        if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+        if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
+    }
+    sv.pend = false;
+    return rc;
+}
+// associateLandmark(z) through the served round
+int serve_associate(nuslam_batch* h, double r, double phi, int* id_out)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (sv.open && sv.trips >= kTickJ) { int rc = serve_end(h); if (rc) return rc; }    // every slot of the round is used
+        if (!sv.open) {
+            int rc = lazy_flush(h);                         // what was recorded without association (the tick's predict) goes first
+            if (!rc) rc = serve_open(h);
+            if (rc) return rc;
+        }
+        double cr, cphi;
+        const int f = serve_pending_flags(h, &cr, &cphi);
+        bool parked = false;
+        int st = 0, id = 0;
+        int rc = serve_roundtrip(h, f | DA_F_SCAN, sv.pend ? sv.p_id : 0, r, phi, cr, cphi, &id, &st, &parked);
+        if (rc) return rc;
+        if (parked) {
+            // the round had closed itself (no call for srv.timeout_us): the pending correction through the per-call kernels, then a new round
+            if (sv.pend) {
+                const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
+                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+                if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
+                sv.pend = false;
+                if (rc) return rc;
+            }
+            continue;
+        }
+        sv.pend = false;
+        sv.z_valid = true; sv.z_r = r; sv.z_phi = phi;
+        sv.used = true;
+        *id_out = id;
+        if (st != 0) { sv.clear_status = true; return st; }     // a full map / singular psi: reported from inside this very call
+        return NUSLAM_OK;
+    }
+    return serve_poison(h);                                 // (three rounds in a row closed under the caller's feet)
+}
+// update() while a served round is open: the decision travels with the caller's NEXT call (the next associateLandmark, or the end of
+// the round); a second update() in a row sends the first one on its own
+int serve_update(nuslam_batch* h, double r, double phi, int id, bool init)
+{
+    nuslam_batch::Serve& sv = h->srv;
+    if (sv.pend) {
+        if (sv.trips >= kTickJ) { int rc = serve_end(h); if (rc) return rc; }
+        else {
+            double cr, cphi;
+            const int f = serve_pending_flags(h, &cr, &cphi);
+            bool parked = false;
+            int st = 0;
+            int rc = serve_roundtrip(h, f, sv.p_id, 0.0, 0.0, cr, cphi, nullptr, &st, &parked);
+            if (!rc && parked) {
+                const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
+                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+                if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
+            }
+            sv.pend = false;
+            sv.z_valid = false;                             // (the scanned marker has had its correction: a further one brings its own z)
+            if (rc) return rc;
+        }
+    }
+    if (!sv.open) return -1;                                // (the round is gone: the caller records the update the lazy way)
+    sv.pend = true; sv.p_id = id; sv.p_init = init; sv.p_r = r; sv.p_phi = phi;
+    return NUSLAM_OK;
+}
+
 // ---- the class API driven call by call (nuslam_ekf_predict / _init_landmark / _update), recorded and applied as ONE tick
 // What the caller's loop (slam.cpp:269-318) has asked for since the last flush goes to the device: the recorded predict rides in
 // the first round's k_tick_front launch, the recorded update() calls are its corrections in MODE_FORCE (the caller has taken the
@@ -1034,7 +1257,14 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
 int lazy_flush(nuslam_batch* h)
 {
     nuslam_batch::Lazy& z = h->lazy;
-    if (z.busy || z.empty()) return NUSLAM_OK;
+    if (z.busy) return NUSLAM_OK;
+    if (h->srv.open) {                                  // the served round ends here: its last correction and the pass over P
+        z.busy = true;
+        const int src = serve_end(h);
+        z.busy = false;
+        if (src) return src;
+    }
+    if (z.empty()) return NUSLAM_OK;
     z.busy = true;
     struct Done {
         nuslam_batch::Lazy& z;
@@ -1258,7 +1488,12 @@ void free_batch(nuslam_batch* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->srv.open) {                                     // a resident served round: tell it to end (it would park by itself otherwise)
+        h->srv.pend = false;
+        (void)serve_end(h);
+    }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->srv.mail) (void)hipHostFree(h->srv.mail);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
                      h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
@@ -2159,6 +2394,7 @@ int nuslam_ekf_set_lazy(nuslam_ekf_t* h, int enable)
     if (!h) return NUSLAM_E_ARG;
     int rc = lazy_flush(h->core);
     h->core->lazy.on = enable != 0;
+    h->core->srv.timeout_us = enable > 1 ? enable : 1000;
     return rc;
 }
 
@@ -2225,6 +2461,16 @@ int nuslam_ekf_predict(nuslam_ekf_t* h, double dth, double dx, double dy)
         int lrc = lazy_flush(c);
         if (lrc) return lrc;
         if (c->poisoned) return NUSLAM_E_SYNC;
+        if (c->srv.used && serve_usable(c)) {
+            // the last tick associated its markers: this one will too (slam.cpp:291) -- predict and the next served round are
+            // launched now, behind the pass over P, so that the first associateLandmark finds the round waiting for it
+            c->srv.used = false;
+            TwistArg tw;
+            tw.tw = nullptr; tw.stride = 0; tw.off = 0; tw.dth0 = dth; tw.dx0 = dx;
+            int rc = do_predict(c, tw);
+            if (!rc) rc = serve_open(c);
+            return rc;
+        }
         c->lazy.has_predict = true; c->lazy.dth = dth; c->lazy.dx = dx;
         return NUSLAM_OK;
     }
@@ -2247,6 +2493,10 @@ int nuslam_ekf_update(nuslam_ekf_t* h, double range, double bearing, int id)
             if (z.pi_id == id && z.pi_r == range && z.pi_phi == bearing) { init = 1; z.pend_init = false; }   // slam.cpp:295-297, :318
             else { int lrc = lazy_flush(c); if (lrc) return lrc; }        // an unrelated initializeLandmark: apply it on its own first
         }
+        if (c->srv.open) {                                 // in a served round (associateLandmark in the loop): with the next command
+            const int src = serve_update(c, range, bearing, id, init != 0);
+            if (src >= 0) return src;
+        }
         z.r.push_back(range); z.phi.push_back(bearing); z.id.push_back(id); z.init.push_back(init);
         if (z.id.size() >= 4 * (size_t)kTickJ) return lazy_flush(c);      // (bounded record: four rounds)
         return NUSLAM_OK;
@@ -2259,6 +2509,10 @@ int nuslam_ekf_associate(nuslam_ekf_t* h, double range, double bearing, int* id_
     if (!h || !id_out) return NUSLAM_E_ARG;
     nuslam_batch* c = h->core;
     HIPCHK(hipSetDevice(c->device));
+    if (serve_usable(c)) {
+        if (c->lazy.pend_init) { int lrc = lazy_flush(c); if (lrc) return lrc; }   // (an initializeLandmark no update() followed)
+        return serve_associate(c, range, bearing, id_out);
+    }
     { int lrc = lazy_flush(c); if (lrc) return lrc; }
     int rc = do_associate(c, inline_obs(range, bearing, 0, 0));
     if (!rc) rc = associate_finish(c);

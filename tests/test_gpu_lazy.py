@@ -163,3 +163,116 @@ def test_bad_id_is_reported_by_the_call_itself(hip):
     assert e.value.code == hip.E_BOUNDS
     f.sync()
     assert f.status() == 0
+
+
+# ------------------------------------------------------------------------------------------------ unknown association
+def drive_with_association(f, tw, r, phi, total):
+    """slam.cpp:250-319 as written: associateLandmark in front of every marker; returns the ids it answered."""
+    seen = f.seen                                                       # :251
+    f.predict(tw[0], tw[1])                                             # :269
+    ids = []
+    for i in range(len(r)):
+        k = f.associate(r[i], phi[i])                                   # :291
+        ids.append(k)
+        if k > seen:
+            f.init_landmark(r[i], phi[i], k)                            # :295-297
+        elif k < 0:
+            continue                                                    # :298-300
+        elif k > total:
+            break                                                       # :301-316
+        f.update(r[i], phi[i], k)                                       # :318
+    return ids
+
+
+def served_pair(hip, n, Qm, exact):
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R)                    # lazy: the tick is a round served to the host
+    b = hip.EKF(np.zeros(3), np.zeros(2 * n), Qm, R)
+    b.set_lazy(False)                                                   # k_associate + k_update per call
+    if exact:
+        a.as_batch().set_pass_variant(hip.PASS_EXACT)
+    return a, b
+
+
+@pytest.mark.parametrize("n,m,sigma,exact,park_us", [(12, 5, 1e-3, True, 0), (40, 16, 1e-3, True, 0), (70, 37, 1e-3, True, 0),
+                                                     (35, 16, None, True, 0), (40, 16, 1e-3, False, 0), (40, 16, 1e-3, True, 5)])
+def test_served_round_equals_per_call_kernels_cold_start(hip, n, m, sigma, exact, park_us):
+    """The class API with associateLandmark in the loop: every verdict (match, new landmark, gray zone), `seen`, and -- with the
+    exact chain as the pass -- every bit of state and covariance are the per-call kernels' (k_associate + k_update).  park_us: the
+    served round closes itself after that many microseconds without a call -- from Python that is every call -- and is re-opened:
+    same results."""
+    T = 8
+    tr = synth.make_trace(n, T, m, straight_every=3, noise_sigma=sigma)
+    a, b = served_pair(hip, n, Q, exact)
+    if park_us:
+        a.set_lazy(park_us)
+    nv = 0
+    for t in range(T):
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+        ia = drive_with_association(a, tr.tw[t], r, phi, n)
+        ib = drive_with_association(b, tr.tw[t], r, phi, n)
+        assert ia == ib, (t, ia, ib)
+        nv += len(ia)
+        assert a.seen == b.seen
+        if exact:
+            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov), "tick %d" % t
+        else:
+            Pa, Pb = a.cov, b.cov
+            fin = np.abs(Pb) < 1e9
+            assert np.array_equal(Pa[~fin], Pb[~fin])
+    assert nv > 0 and a.status() == b.status()
+
+
+def test_served_round_warm_map_gray_zone_new_landmark_and_full_map(hip):
+    n, n_world, m, T = 30, 24, 8, 6
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    lm = synth.make_landmarks(n_world)
+    tr = synth.make_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
+    a, b = served_pair(hip, n, Qs, True)
+    for f in (a, b):
+        f.tick(np.zeros(3), bx, by, known_ids=wid)
+    kinds = set()
+    for t in range(T):
+        mx, my = tr.mx[t].copy(), tr.my[t].copy()
+        if t == 2:
+            mx[3] += 0.08                                               # off a landmark by 8 cm: gray zone
+        if t == 3:
+            mx[5], my[5] = 7.0, -6.5                                    # far from everything: a new landmark
+        r, phi = polar(hip, mx, my)
+        ia = drive_with_association(a, tr.tw[t], r, phi, n)
+        ib = drive_with_association(b, tr.tw[t], r, phi, n)
+        assert ia == ib, (t, ia, ib)
+        kinds.update("gray" if k < 0 else ("new" if k > n_world else "match") for k in ia)
+        assert a.seen == b.seen
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov), "tick %d" % t
+    assert kinds == {"gray", "new", "match"}, kinds
+    # two update() calls after one associateLandmark, an update() with another z than the marker associated, a getter in mid-tick
+    r, phi = polar(hip, tr.mx[T - 1], tr.my[T - 1])
+    got = []
+    for f in (a, b):
+        f.predict(0.0, 0.0)
+        k0 = f.associate(r[0], phi[0])
+        f.update(r[0], phi[0], int(tr.ids[T - 1][0]))
+        f.update(r[1], phi[1], int(tr.ids[T - 1][1]))
+        k2 = f.associate(r[2], phi[2])
+        f.update(r[2] + 1e-3, phi[2], int(tr.ids[T - 1][2]))
+        _ = f.state
+        k3 = f.associate(r[3], phi[3])
+        f.update(r[3], phi[3], int(tr.ids[T - 1][3]))
+        got.append((k0, k2, k3))
+    assert got[0] == got[1]
+    assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+
+
+def test_served_round_full_map_is_reported_from_inside_the_call(hip):
+    n = 6
+    a = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R)
+    lm = synth.make_landmarks(n)
+    bx, by, wid = synth.warmup_observations(lm)
+    a.tick(np.zeros(3), bx, by, known_ids=wid)                          # seen == n: the map is full
+    a.predict(0.0, 0.01)
+    with pytest.raises(hip.NuslamError) as e:
+        a.associate(3.0, 0.5)                                           # slam_library.cpp:206-207 indexes out of bounds
+    assert e.value.code == hip.E_BOUNDS
+    a.sync()
+    assert a.status() == 0 and a.seen == n
