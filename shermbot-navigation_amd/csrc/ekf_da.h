@@ -550,6 +550,9 @@ struct DaServe {
     const long long* cmd;    // host (mapped, pinned): [0] (seq << 32) | (flags << 24) | id   [1] r  [2] phi  [3] checksum
                              //                        [4] [5] the correction's own (r, phi) when DA_F_ZOVR   [6] [7] unused
     long long* ans;          // host (mapped, pinned): [0] (seq << 32) | (unsigned)id   [1] (seq << 32) | kind << 28 | status << 24 | seen
+    long long* keys;         // host (mapped, pinned): [nwg] (seq << 32) | key -- every workgroup's verdict on the marker of command seq goes
+                             // STRAIGHT to the host (which takes the minimum and decodes it, decode_association's rule), before the
+                             // workgroups meet: the meet, the drain in front of it and the next trip's top then run beside the host's turn
     int seq0;                // sequence number of the first command of this launch
     int timeout_ticks;       // 100 MHz ticks workgroup 0 waits for a command before it closes the round by itself
 };
@@ -719,7 +722,8 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                 if (key != kNoKey && (key & 3) == 0) match_id = key >> 2;
             }
             const int seq = srv.seq0 + st + 1;
-            if (st >= 0 && wg == 0 && tid == 0) da_answer(srv, seq - 1, ans_id, seen, status, 0);
+            // (a scanning command is answered by the workgroups' keys themselves, see below; any other by this word)
+            if (st >= 0 && wg == 0 && tid == 0 && !scanned) da_answer(srv, seq - 1, ans_id, seen, status, 0);
             // ... and the caller's next call comes back
             da_wait_cmd(srv, seq, wg, d.fwd + 8 * (size_t)b, cmd_sh, &cmd_expired_sh);
             const long long w0 = cmd_sh[0];
@@ -1163,6 +1167,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
             }
             key1 = wave_min(key1);
             meet_sh[0] = key1;                                          // (every lane holds the minimum)
+            if (SERVED && scanned && lane == 0) st_system(srv.keys + wg, ((long long)(srv.seq0 + st + 1) << 32) | (long long)(unsigned)key1);
         }
         DCK(8);
         // ---- meet the other workgroups of this filter: everything stored above has left, then the tagged key slot; the

@@ -161,7 +161,7 @@ struct nuslam_batch {
     // ... with associateLandmark() in the loop (slam.cpp:291): a resident round kernel that takes the caller's calls from a mailbox in
     // mapped pinned host memory (k_da_round<T, true>, csrc/ekf_da.h "a round SERVED to the host")
     struct Serve {
-        long long* mail = nullptr;             // [0..7] the command, [8..9] the answer (two cache lines)
+        long long* mail = nullptr;             // [0..7] the command, [8..9] the answer (two cache lines), [16 .. 16 + nwg) the workgroups' keys
         int seq = 0;                           // sequence number of the last command sent
         bool open = false;                     // a served round is resident on the device
         int trips = 0;                         // commands of this round the device has carried out
@@ -1046,6 +1046,7 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
 }
 
 // ---- the served round (unknown association driven call by call): host side of csrc/ekf_da.h "a round SERVED to the host"
+int get_seen(nuslam_batch* h, int b, int* seen);
 bool serve_usable(const nuslam_batch* h)
 {
     return h->lazy.on && h->B == 1 && h->n >= 1 && h->tick_mode != 0 && h->tick_mode != 2 && !h->deferred && !h->dense_predict &&
@@ -1057,15 +1058,21 @@ int serve_open(nuslam_batch* h)
     { int erc = ensure_tick_buffers(h); if (erc) return erc; }
     { int erc = ensure_da_buffers(h); if (erc) return erc; }
     if (!sv.mail) {
-        HIPCHK(hipHostMalloc((void**)&sv.mail, sizeof(long long) * 32, hipHostMallocMapped));
-        for (int i = 0; i < 32; ++i) sv.mail[i] = 0;
+        const int words = 16 + roundup(h->da.nwg, 8);
+        HIPCHK(hipHostMalloc((void**)&sv.mail, sizeof(long long) * words, hipHostMallocMapped));
+        for (int i = 0; i < words; ++i) sv.mail[i] = 0;
+    }
+    if (!h->host_seen_valid) {                              // the host decodes the verdicts itself: it needs `seen` exactly
+        int seen = 0;
+        int grc = get_seen(h, 0, &seen);
+        if (grc) return grc;
     }
     if (h->poisoned) return NUSLAM_E_SYNC;
     h->last_tick = -1;
     TickObs o = make_tick_obs(h, inline_obs(0.0, 0.0, 0, 0), 0, kTickJ, nullptr, nullptr, nullptr);
     o.log_slot0 = -1;
     DaServe ds;
-    ds.cmd = sv.mail; ds.ans = sv.mail + 8; ds.seq0 = sv.seq + 1; ds.timeout_ticks = sv.timeout_us * 100;
+    ds.cmd = sv.mail; ds.ans = sv.mail + 8; ds.keys = sv.mail + 16; ds.seq0 = sv.seq + 1; ds.timeout_ticks = sv.timeout_us * 100;
     const View v = h->view();
     double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
     int rc = NUSLAM_OK;
@@ -1091,11 +1098,44 @@ void serve_send(nuslam_batch* h, int flags, int id, double r, double phi, double
 }
 // the device's answer to command sv.seq: 0 = carried out (id / seen / status filled in), 1 = the round had parked: the command was
 // NOT taken; < 0: nothing came back (NUSLAM_E_SYNC)
-int serve_wait(nuslam_batch* h, int* id, int* seen, int* status)
+int serve_wait(nuslam_batch* h, bool scan, int* id, int* seen, int* status)
 {
     nuslam_batch::Serve& sv = h->srv;
     volatile long long* a = sv.mail + 8;
     const auto t0 = std::chrono::steady_clock::now();
+    if (scan) {
+        // the verdict comes as every workgroup's key (min over its candidates of 4 k + outcome): the minimum, decoded as
+        // decode_association does on the device (slam_library.cpp:197-200, 206-207, 238-252) -- the device does the same for itself
+        volatile long long* keys = sv.mail + 16;
+        const int nwg = h->da.nwg;
+        int got = 0, kmin = kNoKey;
+        for (unsigned spin = 1;; ++spin) {
+            while (got < nwg) {
+                const long long w = keys[got];
+                if ((int)(w >> 32) != sv.seq) break;
+                const int k = (int)(unsigned)(w & 0xffffffffll);
+                kmin = k < kmin ? k : kmin;
+                ++got;
+            }
+            if (got == nwg) break;
+            const long long a1 = a[1];
+            if ((int)(a1 >> 32) == sv.seq && (((unsigned)(a1 & 0xffffffffll) >> 28) & 1u)) return 1;      // parked
+            __builtin_ia32_pause();
+            if ((spin & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return -1;
+        }
+        const int n = h->n, s0 = h->host_seen[0];
+        int rid = -1, ns = s0, st = 0;
+        if (s0 == 0) { ns = 1; rid = 1; }
+        else if (s0 >= n) { rid = -1; st = NUSLAM_E_BOUNDS; }
+        else if (kmin == kNoKey) { ns = s0 + 1; rid = ns; }
+        else if ((kmin & 3) == 0) rid = kmin >> 2;
+        else if ((kmin & 3) == 1) rid = -1;
+        else { rid = -1; st = NUSLAM_E_SINGULAR; }
+        if (id) *id = rid;
+        if (seen) *seen = ns;
+        if (status) *status = st;
+        return 0;
+    }
     for (unsigned spin = 1;; ++spin) {
         const long long a0 = a[0], a1 = a[1];
         if ((int)(a0 >> 32) == sv.seq && (int)(a1 >> 32) == sv.seq) {
@@ -1139,7 +1179,7 @@ int serve_roundtrip(nuslam_batch* h, int flags, int id, double r, double phi, do
     nuslam_batch::Serve& sv = h->srv;
     serve_send(h, flags, id, r, phi, cr, cphi);
     int seen = 0, st = 0, rid = 0;
-    const int k = serve_wait(h, &rid, &seen, &st);
+    const int k = serve_wait(h, (flags & DA_F_SCAN) != 0, &rid, &seen, &st);
     if (k < 0) return serve_poison(h);
     *parked_out = k == 1;
     if (k == 1) return serve_close(h, sv.trips);           // trips executed incl. the parking one = trips + 1; slots = that - 1
