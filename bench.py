@@ -41,10 +41,19 @@ sys.path.insert(0, os.path.join(ROOT, "shermbot-navigation_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TARGET_TIMED_S = 0.100  # the timed blocks must add up to at least this
-MAX_BLOCKS = 400
-# rough step times (ms) only to size the resident trace; the number of blocks actually run is decided by the clock
-STEP_MS_GUESS = {"ekf1000": 0.05, "da1000": 0.1, "batch": 2.0, "ekf5000": 20.0}
+# the timed blocks must add up to at least this (ms), per workload: a 0.1 s region is thin beside a 20 s command (the driver's
+# utilisation samples never saw it); the single-filter workloads time 2 s, the batch 1 s, the 33 ms steps of ekf5000 0.5 s
+MIN_TIMED_MS = {"ekf1000": 2000.0, "da1000": 2000.0, "batch": 1000.0, "ekf5000": 500.0}
+MIN_BLOCKS = 5          # ... and never fewer than this many K-step blocks (the reported figure is the median block)
+MAX_BLOCKS = 5000
+# rough step times (ms) only to size the resident trace (taken a little LOW: the trace must hold enough ticks even on a fast box);
+# the number of blocks actually run is decided by the clock
+STEP_MS_GUESS = {"ekf1000": 0.040, "da1000": 0.085, "batch": 0.75, "ekf5000": 30.0}
+
+
+# what the input is (synth.make_wellposed_trace / the simulator's fov, min_range): NOT SURVEY 8(d)'s all-around "m nearest" trace, on
+# which the reference algorithm itself is chaotic at the level of one ulp (tests/test_trace_conditioning.py)
+TRACE_KIND = "wellposed: fov 2.0 rad, min_range 0.2 m, the m nearest landmarks inside it, wheel increments dL 5/16, dR 3/8 rad per tick"
 
 
 def parse():
@@ -93,7 +102,7 @@ def parse():
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
     ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
-    ap.add_argument("--min-timed-ms", type=float, default=1e3 * TARGET_TIMED_S)
+    ap.add_argument("--min-timed-ms", type=float, default=None, help="the timed blocks add up to at least this (default per workload: MIN_TIMED_MS)")
     ap.add_argument("--blocks", type=int, default=0, help="run exactly this many timed K-step blocks (0: until --min-timed-ms)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="attach the per-dispatch HIP events inside the timed region itself (costs throughput: every "
@@ -269,6 +278,76 @@ def api_driven(n, m, tr, bx, by, wid, Q, R):
     return res
 
 
+def da_parity(nh, args, n, m, Q, R, dtype, dev, seed):
+    """The da1000 line's same-run parity leg: associateLandmark + update per marker (slam_library.cpp:188-282 in the loop
+    slam.cpp:279-318) for `--parity-ticks` ticks of the line's own kind of input, oracle (structured mode, marker by marker) against
+    the GPU through nuslam_batch_run with the timed handle's settings; the ids come from a twin filter stepped with nuslam_ekf_tick
+    (same kernels), which must equal the nuslam_batch_run filter bit for bit."""
+    import numpy as np
+    from nuslam_hip import synth
+    O_ = __import__("_oracle")
+    T = int(args.parity_ticks)
+    n_world = n - 1
+    tr = synth.make_wellposed_trace(n_world, T, m, seed=seed, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(tr.landmarks, seed=seed, noise_sigma=1e-4)
+    O_.set_threads(O_.usable_cpus())
+    o = O_.OracleEKF(np.zeros(3), np.zeros(2 * n), Q, R, O_.ORC_STRUCTURED)
+    o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=wid)
+    snap = (o.state.copy(), o.cov.copy(), o.seen)
+    ids_o = np.zeros((T, m), dtype=np.int64)
+    seen_o = np.zeros(T, dtype=np.int64)
+    margin = np.inf
+    for t in range(T):
+        o.predict(tr.tw[t][0], tr.tw[t][1])
+        cached = o.seen
+        for i in range(m):
+            z = O_.cartesian2polar(tr.mx[t, i], tr.my[t, i])
+            k, dk = o.associate(z[0], z[1], want_d=True)
+            dk = dk[~np.isnan(dk)]
+            if dk.size:
+                margin = min(margin, float(np.min(np.abs(dk - 0.01) / 0.01)), float(np.min(np.abs(dk - 60.0) / 60.0)))
+            ids_o[t, i] = k
+            if k > cached:
+                o.init_landmark(z[0], z[1], k)
+            elif k < 0:
+                continue
+            o.update(z[0], z[1], k)
+        seen_o[t] = o.seen
+    O_.set_threads(1)
+    g = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
+    h = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
+    ids_equal = seen_equal = True
+    for f in (g, h):
+        f.restore(*snap)
+        fb = f.as_batch()
+        if args.tick_mode is not None:
+            fb.set_tick_mode(args.tick_mode)
+        if args.pass_variant is not None:
+            fb.set_pass_variant(args.pass_variant)
+    for t in range(T):
+        idg = g.tick(tr.tw[t], tr.mx[t], tr.my[t])
+        ids_equal = ids_equal and bool(np.array_equal(idg, ids_o[t]))
+        seen_equal = seen_equal and g.seen == seen_o[t]
+    hb = h.as_batch()
+    hb.load_trace(tr.tw[:, :2], tr.mx, tr.my, None, bcast=True)
+    hb.run(0, T)
+    gs, gP, os_, oP = h.state, h.cov, o.state, o.cov
+    floor = 1e-12 * np.abs(oP).max()
+    return {"against": "oracle/nuslam_oracle.c, structured mode, driven marker by marker as slam.cpp:269-318 (EKF parity unpinned, see "
+                       "DESIGN.md); input trace " + TRACE_KIND + "; marker noise 1e-4 m",
+            "path": "nuslam_batch_run on a resident trace without ids (tick mode %s, pass variant %s); ids from a twin filter stepped with "
+                    "nuslam_ekf_tick" % ("default" if args.tick_mode is None else args.tick_mode,
+                                         "default" if args.pass_variant is None else args.pass_variant),
+            "ticks": T, "associations": int(T * m), "ids_equal_every_tick": bool(ids_equal), "seen_equal_every_tick": bool(seen_equal),
+            "matches": int((ids_o > 0).sum()), "gray_zone": int((ids_o < 0).sum()),
+            "min_relative_margin_of_any_decision_distance_from_a_threshold": float(margin),
+            "batch_run_equals_tick_by_tick_bitwise": bool(np.array_equal(gs, g.state) and np.array_equal(gP, g.cov)),
+            "device_status": int(h.status()),
+            "max_rel_err_state": float((np.abs(gs - os_) / np.maximum(np.abs(os_), 1e-12)).max()),
+            "max_rel_err_cov": float((np.abs(gP - oP) / np.maximum(np.abs(oP), floor)).max()),
+            "tolerance": 1e-6}
+
+
 def pmc_traffic(nh, sweep_kernel_sig, min_bytes):
     """HBM bytes per launch from a committed rocprofv3 --pmc measurement (profiles/r*/**pmc_hbm*.json made by
     tools/summarize_pmc.py), quoted ONLY when that record was taken from the very kernel sources the loaded library
@@ -340,7 +419,9 @@ def main():
 
     # how many K-step blocks the resident trace must hold: enough for >= the timed target even if the code were several
     # times faster than today, plus one block for the kernel-event pass
-    blocks_cap = int(min(MAX_BLOCKS, max(1, np.ceil(args.min_timed_ms / (K * STEP_MS_GUESS[args.workload] * (B / 1024.0 if args.workload == "batch" else 1.0))))))
+    if args.min_timed_ms is None:
+        args.min_timed_ms = MIN_TIMED_MS[args.workload]
+    blocks_cap = int(min(MAX_BLOCKS, max(MIN_BLOCKS, np.ceil(args.min_timed_ms / (K * STEP_MS_GUESS[args.workload] * (B / 1024.0 if args.workload == "batch" else 1.0))))))
     if args.blocks > 0:
         blocks_cap = args.blocks
     ticks_total = W + K * (blocks_cap + 1)
@@ -462,7 +543,7 @@ def main():
         block_s.append(time.perf_counter() - t0)
         bt.sync()                      # the handle's status words (two small device-to-host copies): checked, not timed
         t_at += K
-        if world == 1 and args.blocks == 0 and sum(block_s) >= 1e-3 * args.min_timed_ms:
+        if world == 1 and args.blocks == 0 and len(block_s) >= MIN_BLOCKS and sum(block_s) >= 1e-3 * args.min_timed_ms:
             break                      # (with several ranks every rank runs the same, precomputed number of blocks)
     if not in_region:
         # kernel durations: the next K steps of the same trace, every dispatch bracketed by its own HIP events
@@ -559,6 +640,7 @@ def main():
                    "ranks_seen_by_backend": ranks_seen, "backend": (args.backend if world > 1 else None),
                    "trace": "per-filter, generated on the device (k_sim_path / k_sim_markers)" if trace_kind == "device"
                             else "one host-made trace per rank, resident in HBM",
+                   "trace_kind": TRACE_KIND + ("" if known else "; marker noise 1e-4 m, %d of %d map slots filled" % (n_world, n)),
                    "kernel_events_in_timed_region": in_region, "Q_diag": float(Q[0, 0]), "R_diag": float(R[0, 0])},
         "timing": {"blocks": int(block_s.size), "steps_per_block": K, "timed_region_ms": 1e3 * float(block_s.sum()),
                    "ms_per_step_median": 1e3 * dt_med / K, "ms_per_step_min": 1e3 * float(block_s.min()) / K,
@@ -628,6 +710,11 @@ def main():
                                    "of this build (null when no record matches nuslam_build_info())"}
         if exact_pass:
             out["roofline"]["exact_pass_behind_it"] = exact_pass
+        # ... and the same bytes over the WHOLE tick (every kernel of it, launch gaps included): what the chip's HBM sees of a tick
+        tick_s = dt_med / K
+        out["roofline"]["whole_tick"] = {"bytes_per_step": min_bytes, "ms_per_step": 1e3 * tick_s, "GBps": min_bytes / tick_s / 1e9,
+                                         "frac": min_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
+                                         "note": "2*L^2*w*B / ms_per_step: the pass's bytes over the wall time of a whole tick"}
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
@@ -712,7 +799,7 @@ def main():
         gs, gP, os_, oP = g2.state, g2.cov, os2.state.copy(), os2.cov.copy()
         floor = 1e-12 * np.abs(oP).max()
         out["parity"] = {"against": "oracle/nuslam_oracle.c, structured mode (the reference's algebra with exact-zero terms skipped; "
-                                    "EKF parity unpinned, see DESIGN.md)",
+                                    "EKF parity unpinned, see DESIGN.md); input trace " + TRACE_KIND,
                          "path": "nuslam_batch_run on a resident trace with the timed handle's settings (overlap %s, pass variant %s)"
                                  % ("off" if args.no_overlap else "default", "default" if args.pass_variant is None else args.pass_variant),
                          "structured_oracle_equals_dense_oracle_bitwise_on_first_%d_ticks" % orc_ticks: dense_equal,
@@ -723,6 +810,8 @@ def main():
                          "seen_equal": bool(g2.seen == os2.seen), "tolerance": 1e-6}
         if not args.no_api:
             out["api_driven"] = api_driven(n, m, ptr, bx, by, wid, Q, R)
+    if args.workload == "da1000" and world == 1 and args.cpu_seconds > 0:
+        out["parity"] = da_parity(nh, args, n, m, Q, R, dtype, dev, seed)
     print(json.dumps(out))
     sys.stdout.flush()
     if world > 1:

@@ -153,3 +153,109 @@ def test_config3_batch_n200_t100_four_filters(hip):
         for cp, (es, ep) in zip(checkpoints, rows):
             assert es < TOL and ep < TOL, "%s: tick %d: state %.2e covariance %.2e" % (name, cp, es, ep)
     O.set_threads(1)
+
+
+# ------------------------------------------------------------------------------------------- configs[4] at depth
+def test_config4_unknown_association_n1000_t100_at_depth(hip):
+    """associateLandmark in front of every correction (slam_library.cpp:188-253 in the loop slam.cpp:279-318), N = 1000,
+    T = 100 ticks x 16 markers on the bench's da1000 input (well-posed trace, 1e-4 m marker noise, Q = diag(1e-4), the map
+    never full), on the DEFAULT path -- k_da_round (resident round) or k_da_begin + k_da_step per marker, each followed by the
+    rank-2m pass k_tick_rank -- against the oracle's structured mode driven marker by marker:
+
+      * the id every marker resolves to and `seen` equal the oracle's at EVERY tick (ids come from nuslam_ekf_tick, which runs
+        the same kernels as nuslam_batch_run; a second filter goes through nuslam_batch_run in four runs and must equal the first
+        bit for bit at the checkpoints);
+      * every Mahalanobis distance a decision depends on keeps a >= 1e-6 relative margin from the 0.01 / 60 thresholds
+        (slam_library.cpp:193-194), so rounding cannot legitimately flip a verdict -- asserted on the oracle's distances;
+      * state / covariance within 1e-6 per entry at ticks {1, 10, 50, 100};
+      * after tick 10: new landmarks (first sightings: the round goes through the exact chain on the device) re-observed
+        later, and gray-zone markers (skipped).
+    The served round of the class API (tests/test_gpu_lazy.py) runs the same kernel."""
+    n, n_world, m, T = 1000, 990, 16, 100
+    checkpoints = (1, 10, 50, 100)
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    lm = synth.make_landmarks(n_world)
+    tr = synth.make_wellposed_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
+    mx, my = tr.mx.copy(), tr.my.copy()
+    # new landmarks far outside the grid at ticks 15, 40, 70 (ids 991, 992, 993), each re-observed three ticks later from the true
+    # pose; gray-zone markers (a known landmark seen 5 cm off) at ticks 20, 45, 80
+    news = {}
+    for j, t0 in enumerate((15, 40, 70)):
+        slot = 3 + j
+        mx[t0, slot], my[t0, slot] = 18.0 + 3.0 * j, 1.0 - 2.0 * j
+        th, x, y = tr.truth[t0]
+        w = np.array([x + np.cos(th) * mx[t0, slot] - np.sin(th) * my[t0, slot], y + np.sin(th) * mx[t0, slot] + np.cos(th) * my[t0, slot]])
+        th, x, y = tr.truth[t0 + 3]
+        d = w - np.array([x, y])
+        mx[t0 + 3, slot + 6], my[t0 + 3, slot + 6] = np.cos(th) * d[0] + np.sin(th) * d[1], -np.sin(th) * d[0] + np.cos(th) * d[1]
+        news[t0] = (slot, n_world + 1 + j)
+    for t0 in (20, 45, 80):
+        mx[t0, 9] += 0.05
+
+    O.set_threads(O.usable_cpus())
+    o = O.OracleEKF(np.zeros(3), np.zeros(2 * n), Qs, R, O.ORC_STRUCTURED)
+    o.tick(tw=np.zeros(3), mx=bx, my=by, known_ids=wid)
+    assert o.seen == n_world
+    snap = (o.state.copy(), o.cov.copy(), o.seen)
+    # the oracle, marker by marker (slam.cpp:269-318 by hand), recording ids, `seen`, the decision margins and the checkpoints
+    ids_o = np.zeros((T, m), dtype=np.int64)
+    seen_o = np.zeros(T, dtype=np.int64)
+    margins = []
+    ref = {}
+    for t in range(T):
+        o.predict(tr.tw[t][0], tr.tw[t][1])
+        cached = o.seen
+        for i in range(m):
+            z = O.cartesian2polar(mx[t, i], my[t, i])
+            k, dk = o.associate(z[0], z[1], want_d=True)
+            dk = dk[~np.isnan(dk)]
+            if dk.size:
+                margins.append(float(min(np.min(np.abs(dk - 0.01) / 0.01), np.min(np.abs(dk - 60.0) / 60.0))))
+            ids_o[t, i] = k
+            if k > cached:
+                o.init_landmark(z[0], z[1], k)
+            elif k < 0:
+                continue
+            o.update(z[0], z[1], k)
+        seen_o[t] = o.seen
+        if t + 1 in checkpoints:
+            ref[t + 1] = (o.state.copy(), o.cov.copy())
+    O.set_threads(1)
+    assert min(margins) >= 1e-6, "a candidate distance sits on a threshold (%.2e): the trace proves nothing" % min(margins)
+    for t0, (slot, new_id) in news.items():
+        assert ids_o[t0, slot] == new_id and ids_o[t0 + 3, slot + 6] == new_id, (t0, ids_o[t0], ids_o[t0 + 3])
+    assert all(ids_o[t0, 9] == -1 for t0 in (20, 45, 80)), [ids_o[t0, 9] for t0 in (20, 45, 80)]
+    assert (ids_o > 0).mean() > 0.75 and seen_o[-1] == n_world + 3
+
+    for name, mode in (("resident round", 1), ("launch per marker", 2)):
+        g = hip.EKF(np.zeros(3), np.zeros(2 * n), Qs, R)                # tick by tick: the ids
+        g.restore(*snap)
+        g.as_batch().set_tick_mode(mode)
+        h = hip.EKF(np.zeros(3), np.zeros(2 * n), Qs, R)                # nuslam_batch_run on the resident trace: the timed entry point
+        h.restore(*snap)
+        hb = h.as_batch()
+        hb.set_tick_mode(mode)
+        hb.load_trace(tr.tw[:, :2], mx, my, None, bcast=True)
+        done = 0
+        worst = {}
+        for t in range(T):
+            idg = g.tick(tr.tw[t], mx[t], my[t])
+            assert np.array_equal(idg, ids_o[t]), "%s, tick %d: oracle %s gpu %s" % (name, t, ids_o[t], idg)
+            assert g.seen == seen_o[t], (name, t)
+            if t + 1 in checkpoints:
+                hb.run(done, t + 1)
+                done = t + 1
+                gs, gP = g.state, g.cov
+                assert np.array_equal(h.state, gs) and np.array_equal(h.cov, gP) and h.seen == g.seen, \
+                    "%s: nuslam_batch_run and nuslam_ekf_tick part ways by tick %d" % (name, t + 1)
+                os_, oP = ref[t + 1]
+                es, ep = entry_rel_err(gs, os_), entry_rel_err(gP, oP)
+                worst[t + 1] = (es, ep)
+                assert es <= TOL and ep <= TOL, "%s, tick %d: state %.2e cov %.2e" % (name, t + 1, es, ep)
+        assert g.status() == 0 and h.status() == 0
+        print("N=1000 unknown association, %s + rank-2m pass, T=%d x %d: ids and seen equal the oracle's at every tick (%d matches, "
+              "%d new, %d gray-zone; threshold margin %.1e); state / cov vs oracle: %s"
+              % (name, T, m, (ids_o > 0).sum(), len(news), (ids_o < 0).sum(), min(margins),
+                 ", ".join("t%d %.1e / %.1e" % (k, v[0], v[1]) for k, v in sorted(worst.items()))))
+        g.close(); h.close()
