@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--tick-pipeline", action="store_true",
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
-    ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2, 3],
+    ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2, 3, 4],
                     help="nuslam_batch_set_tick_mode: 0 one pass over P per correction, 1 tick pipelines, 2 as 1 but unknown "
                          "association as one launch per marker instead of the resident round kernel")
     ap.add_argument("--pass-variant", type=int, default=None,

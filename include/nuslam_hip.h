@@ -221,6 +221,9 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
  * mode 1 (default): the tick pipeline -- the serial part of all corrections first (a 35 x 35 block and 35 state
  * entries carried through the corrections: H, S^-1, K, the innovation), then the O(len) gain / prior-row strips,
  * then ONE pass over the covariance that carries every tile through all corrections: 2 len^2 w bytes per tick.
+ * For ONE filter the whole tick is one launch where it can be (csrc/ekf_fused.h: predict, chain, strips and the pass over the
+ * covariance as workgroups of one grid -- the pass's tile loads run under the serial chain); mode 4: as 1 with the pass as a launch
+ * of its own behind the front launch; mode 3: chain, strips and pass as three launches (measurement).  Same bits in 1, 3 and 4.
  * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
  * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle.
  * Ticks with UNKNOWN association follow the same switch: mode 1 = tracked rows / columns / diagonal blocks of the

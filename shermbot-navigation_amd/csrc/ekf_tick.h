@@ -473,6 +473,28 @@ struct TickPublish {
     int rank_panels;       // != 0: the strips that follow this chain carry their panels in rank form (the host has proven the round free of
                            // first sightings and the pass is the rank-2m one): the chain stores the entry's KV rows instead of MP / BR
 };
+// k_tick_fused (ekf_fused.h): the pass over P runs as workgroups of the SAME launch and takes K_s / V_s from the strips as they are
+// formed.  The strips then store every value as TWO self-validating 8-byte words { half of the double, tag } (agent-scope
+// stores, no drain, no counter): a consumer accepts an element when both of its words carry this round's tag.
+struct TickTagged {
+    long long* tagK;       // [B][2 kTickJ][ld][2]
+    long long* tagV;
+    int tag;               // this round's tag (never 0: the buffers start zeroed)
+};
+// { half, tag } words of a tagged strip element
+__device__ inline void st_tagged(long long* p, double x, int tag)
+{
+    const long long bits = __double_as_longlong(x);
+    st_agent(p, (long long)(((unsigned long long)(unsigned)tag << 32) | (unsigned long long)(unsigned)(bits >> 32)));
+    st_agent(p + 1, (long long)(((unsigned long long)(unsigned)tag << 32) | (unsigned long long)(unsigned)(bits & 0xffffffffll)));
+}
+// returns false while the element has not arrived
+__device__ inline bool ld_tagged(const long long* p, int tag, double& x)
+{
+    const long long w0 = ld_agent(p), w1 = ld_agent(p + 1);
+    x = __longlong_as_double((long long)(((unsigned long long)w0 << 32) | ((unsigned long long)w1 & 0xffffffffull)));
+    return (int)(w0 >> 32) == tag && (int)(w1 >> 32) == tag;
+}
 constexpr int kPubWords = 4;
 __device__ inline void plan_store(bool publish, double* p, double x)
 {
@@ -1384,13 +1406,14 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
 // entry: same bits.
 constexpr int kPlanWords = (int)(sizeof(TickStep) / 8);
 
-template <typename T>
+// TAGGED (k_tick_fused only): rank-form strips whose K / V go out as tagged words (tg) instead of into Kbuf / Vbuf
+template <typename T, bool TAGGED = false>
 __device__ inline void tick_panels_stream(const int b, const int wg, View v, TickObs o, const T* __restrict__ P,
                                           const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                           double* __restrict__ Rbuf, double* __restrict__ Vbuf, TickPublish pub,
                                           int* __restrict__ timeouts, const int* __restrict__ posmap = nullptr,
                                           double* __restrict__ KU = nullptr, double* __restrict__ RU = nullptr,
-                                          double* __restrict__ SU = nullptr)
+                                          double* __restrict__ SU = nullptr, TickTagged tg = TickTagged{})
 {
     // posmap != null (streamed overlapped runs, k_tick_strips): the strips at the NEXT tick's index set are also dropped into the
     // compact arrays KU, RU, SU for that tick's chain (tick_carry), as k_tick_panels does
@@ -1539,7 +1562,14 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
                         }
                         double V0 = 0.0, V1 = 0.0;
                         if (Vbuf || RANKP) { V0 = hp_entry(ps->Hc, rs, 0); V1 = hp_entry(ps->Hc, rs, 1); }
-                        if (Vbuf) {
+                        if constexpr (TAGGED) {
+                            // EVERY lane stores to its index's slot -- the four lanes of a quad hold the same value, lanes beyond the
+                            // matrix index 0's -- so the wave's write-through stores merge into whole lines (with three lanes of four
+                            // writing a dump area through to memory the strips took four times as long)
+                            long long* const vt = tg.tagV + (((size_t)b * kTickJ * 2 + st * 2) * ld + tr) * 2;
+                            st_tagged(vt, V0, tg.tag);
+                            st_tagged(vt + (size_t)ld * 2, V1, tg.tag);
+                        } else if (Vbuf) {
                             double* const vd = owner ? Vbuf + (size_t)b * kTickJ * 2 * ld + t : dump;
                             vd[(size_t)(st * 2 + 0) * rsp] = V0;
                             vd[(size_t)(st * 2 + 1) * rsp] = V1;
@@ -1576,10 +1606,16 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
 #pragma unroll
                         for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
                         gain_row(pc, Hc, Si, t, setv, K, m);
-                        double* const kd = owner ? Kb + t : dump;
-                        const size_t ksp = owner ? (size_t)ld : 0;
-                        kd[(size_t)(st * 2 + 0) * ksp] = K[0];
-                        kd[(size_t)(st * 2 + 1) * ksp] = K[1];
+                        if constexpr (TAGGED) {
+                            long long* const kt = tg.tagK + (((size_t)b * kTickJ * 2 + st * 2) * ld + tr) * 2;
+                            st_tagged(kt, K[0], tg.tag);
+                            st_tagged(kt + (size_t)ld * 2, K[1], tg.tag);
+                        } else {
+                            double* const kd = owner ? Kb + t : dump;
+                            const size_t ksp = owner ? (size_t)ld : 0;
+                            kd[(size_t)(st * 2 + 0) * ksp] = K[0];
+                            kd[(size_t)(st * 2 + 1) * ksp] = K[1];
+                        }
                         if (posmap) {                                   // (uniform)
                             cu_dst[(size_t)(st * 2 + 0) * cu_step] = K[0];
                             cu_dst[(size_t)(st * 2 + 1) * cu_step] = K[1];
@@ -1625,8 +1661,11 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         }
     }
     };
-    if (rankp) loop(std::true_type{});
-    else loop(std::false_type{});
+    if constexpr (TAGGED) loop(std::true_type{});
+    else {
+        if (rankp) loop(std::true_type{});
+        else loop(std::false_type{});
+    }
     if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
     if (role == 1 && pm >= 0) SU[(size_t)b * NU + pm] = sv;
 }

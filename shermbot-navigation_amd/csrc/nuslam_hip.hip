@@ -103,6 +103,11 @@ struct nuslam_batch {
     hipEvent_t gpass[4] = { nullptr, nullptr, nullptr, nullptr };   // group g's last pass over P is done
     bool gpass_set[4] = { false, false, false, false };
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
+    int fuse_pass = 1;         // 1: ... and the rank-2m pass over P as workgroups of that launch too (k_tick_fused, ekf_fused.h) in rounds
+                               // the host can prove free of first sightings; 0: the pass as a launch of its own behind it (tick mode 4)
+    long long* tk_tagK = nullptr;   // [B][2 kTickJ][ld][2]: the K / V strips of a fused round as self-validating { half, tag } words
+    long long* tk_tagV = nullptr;
+    unsigned seq_tag = 0;      // the last round's tag (0 is never one)
     double* tk_V = nullptr;    // V_s = H_s R_s strips [B][kTickJ][2][ld]: the second factor of the rank-2m pass (ekf_rank.h)
     // the pass over P of a tick pipeline (nuslam_batch_set_pass_variant): 0 = rank-2m on the matrix cores, the exact chain
     // for rounds with a first sighting; 1 = always the exact chain, plain kernel; 2 = always the exact chain, two-unit
@@ -478,10 +483,10 @@ int ensure_tick_buffers(nuslam_batch* h)
     if (h->tk_ready) return NUSLAM_OK;
     // (a failure partway leaves tk_ready unset: the next call frees what the failed one got and starts over)
     {
-        void* part[] = { h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub };
+        void* part[] = { h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_tagK, h->tk_tagV };
         for (void* p : part)
             if (p) (void)hipFree(p);
-        h->tk_plan = nullptr; h->tk_K = h->tk_R = h->tk_V = nullptr; h->tk_pub = nullptr;
+        h->tk_plan = nullptr; h->tk_K = h->tk_R = h->tk_V = nullptr; h->tk_pub = nullptr; h->tk_tagK = h->tk_tagV = nullptr;
     }
     const int big = 160 * 1024 - 1024;          // gfx950: 160 KB of LDS per CU
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick_apply<double, 8, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, big));
@@ -503,11 +508,19 @@ int ensure_tick_buffers(nuslam_batch* h)
     { int rc = set_rank_attributes(); if (rc) return rc; }
     HIPCHK(hipMalloc(&h->tk_pub, sizeof(int) * kPubWords * (size_t)h->B));
     HIPCHK(hipMemsetAsync(h->tk_pub, 0, sizeof(int) * kPubWords * (size_t)h->B, h->stream));
+    if (h->B == 1) {                                 // (the fused launch is for one filter)
+        const size_t tb = sizeof(long long) * 2 * kTickJ * (size_t)h->ld * 2;
+        HIPCHK(hipMalloc(&h->tk_tagK, tb));
+        HIPCHK(hipMalloc(&h->tk_tagV, tb));
+        HIPCHK(hipMemsetAsync(h->tk_tagK, 0, tb, h->stream));
+        HIPCHK(hipMemsetAsync(h->tk_tagV, 0, tb, h->stream));
+    }
     if (!h->tk_sync) {                             // {chain, next} completion counters, expired waits, probe words
         HIPCHK(hipMalloc(&h->tk_sync, sizeof(int) * 8));
         HIPCHK(hipMemsetAsync(h->tk_sync, 0, sizeof(int) * 8, h->stream));
     }
     h->seq_pub = h->seq_gather = h->seq_pred = 0;
+    h->seq_tag = 0;
     h->tk_ready = true;
     return NUSLAM_OK;
 }
@@ -819,13 +832,29 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             pub.rank_panels = rank_strips ? 1 : 0;
             if (with_predict) pub.tw = *fused_predict;
             else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
-            DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
-                                       (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
-            if (rc) return rc;
+            // ONE filter, the rank-2m pass, no first sighting possible: the pass rides in the same launch (ekf_fused.h)
+            const bool fused = h->fuse_pass && h->B == 1 && h->pass_mode == 0 && h->rank_tile == 0 && !may_init;
+            if (fused) {
+                h->seq_tag += 1u;
+                if (h->seq_tag == 0u) h->seq_tag = 1u;
+                TickTagged tg;
+                tg.tagK = h->tk_tagK; tg.tagV = h->tk_tagV; tg.tag = (int)h->seq_tag;
+                int n_pass = 0;
+                DISPATCH_T(h, n_pass = FusedTile<T>::blocks(h->ld, h->L));
+                DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_fused<T>, dim3(1 + n_pred + strip_wgs + n_pass, 1), dim3(256), v, o, total,
+                                           (T*)h->P(), (T*)h->Palt(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, tg, n_pred, strip_wgs, o.J, h->tk_sync + 2)));
+                if (rc) return rc;
+            } else {
+                DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
+                                           (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
+                if (rc) return rc;
+            }
             h->seq_pub += 2u * kTickJ;
             if (with_predict) { h->seq_gather += 1u; h->seq_pred += (unsigned)n_pred; }
-            rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init, whole(h));
-            if (rc) return rc;
+            if (!fused) {
+                rc = launch_pass(h, v, o.J, h->tk_plan, false, may_init, whole(h));
+                if (rc) return rc;
+            }
         } else {
             DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(h->B), dim3(256), v, o, total,
                                        (const T*)h->P(), h->tk_plan, TickCarry{}, (int*)nullptr, (int*)nullptr)));
@@ -1535,7 +1564,7 @@ void free_batch(nuslam_batch* h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->srv.mail) (void)hipHostFree(h->srv.mail);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_tagK, h->tk_tagV, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -2304,10 +2333,11 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
-    if (!h || mode < -1 || mode > 3) return NUSLAM_E_ARG;
+    if (!h || mode < -1 || mode > 4) return NUSLAM_E_ARG;
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
     h->front = mode != 3;                          // 3: as 1 with the chain and the strips as two launches (measurement)
-    h->tick_mode = mode == 3 ? 1 : mode;
+    h->fuse_pass = mode != 3 && mode != 4;         // 4: as 1 with the pass over P as a launch of its own behind the front (round 3's default)
+    h->tick_mode = (mode == 3 || mode == 4) ? 1 : mode;
     return NUSLAM_OK;
 }
 
@@ -2458,7 +2488,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (rc) return rc;
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
-    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode;
+    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode; d->front = s->front; d->fuse_pass = s->fuse_pass;
     d->touched = s->touched; d->pass_mode = s->pass_mode; d->rank_tile = s->rank_tile; d->apply_units = s->apply_units;
     d->lazy.on = s->lazy.on;
     rc = [&]() -> int {

@@ -223,3 +223,37 @@ def test_rank_form_strips_same_bits_in_every_launch_form(hip, n, m, dtype, cold)
     assert np.array_equal(res[0][0], res[1][0]), "state"
     assert np.array_equal(res[0][1], res[1][1]), "covariance"
     assert res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("n,m,dtype", [(1000, 16, 0), (200, 16, 0), (200, 7, 0), (300, 16, 1), (40, 16, 0)])
+def test_fused_tick_same_bits_as_the_separate_launches(hip, n, m, dtype):
+    """One filter's known-id tick as ONE launch (csrc/ekf_fused.h: predict || chain || strips || the rank-2m pass, whose tile loads
+    run under the serial chain and whose k-steps follow the strips entry by entry) against the same tick with the pass as a launch
+    of its own behind k_tick_front (tick mode 4, round 3's default) and with chain / strips / pass as three launches (mode 3):
+    every element takes k_tick_rank's k-ordered fma chain in all three -- identical bits, tick after tick, with skipped markers,
+    fewer markers than a round, fp32 storage, and a first sighting in mid-run (that round steps aside to the two-launch form)."""
+    T = 12
+    lm = synth.make_landmarks(n)
+    tr = synth.make_wellposed_trace(n, T, m, landmarks=lm, straight_every=4) if n >= 200 else synth.make_trace(n, T, m, straight_every=4, **EXACT_WHEELS)
+    bx, by, wid = synth.warmup_observations(lm)
+    fs = []
+    for mode in (1, 4, 3):
+        f = hip.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype)
+        f.as_batch().set_tick_mode(mode)
+        # the map without its last landmark: that one appears at tick 6 as a first sighting
+        f.tick(np.zeros(3), bx[:-1], by[:-1], known_ids=wid[:-1], want_ids=False)
+        fs.append(f)
+    for t in range(T):
+        ids = tr.ids[t].copy()
+        mx, my = tr.mx[t].copy(), tr.my[t].copy()
+        if t == 3:
+            ids[2] = -1                                                 # a skipped marker
+        if t == 6:
+            ids[1] = n; mx[1], my[1] = bx[-1], by[-1]                   # landmark n for the first time
+        for f in fs:
+            f.tick(tr.tw[t], mx, my, known_ids=ids, want_ids=False)
+        if t in (0, 3, 6, 7, T - 1):
+            s0, P0 = fs[0].state, fs[0].cov
+            for f in fs[1:]:
+                assert np.array_equal(s0, f.state) and np.array_equal(P0, f.cov), "tick %d" % t
+    assert all(f.status() == 0 for f in fs) and len({f.seen for f in fs}) == 1

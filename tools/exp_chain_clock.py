@@ -44,3 +44,5 @@ if not os.environ.get("CHAIN_ONLY"):
     print("k_tick_front timeline (us after the chain workgroup's entry): chain loop start %.2f, loop end %.2f, exit %.2f | predict workgroup %.2f .. %.2f"
           " | strips: middle workgroup %.2f .. %.2f, last workgroup %.2f .. %.2f" % tuple(med[1:10]))
     print("   chain prologue: block gathered and predict applied %.2f | overlapped runs: previous strips complete %.2f, replayed on the block %.2f (plan scalars %.2f, strips loaded %.2f, replay %.2f)" % (med[10], med[13], med[14], med[10], med[11], med[12]))
+    if med[11] != 0:
+        print("   fused pass (a middle workgroup): entry %.2f, first k-step may go %.2f, last k-step may go %.2f, stores issued %.2f" % tuple(med[11:15]))
