@@ -236,15 +236,15 @@ def cpu_baseline(n, m, tr, budget_s, warm_state):
             "ms_per_step": 1e3 * dt / done}, o, cands["oracle-c"][1]
 
 
-def api_driven(n, m, tr, bx, by, wid, Q, R):
+def api_driven(n, m, tr, bx, by, wid, Q, R, exe_name="api_rate"):
     """The rate the UNCHANGED slam node would see: slam_library::ExtendedKalman (the C++ host mirror,
     shermbot-navigation_amd/cpp/nuslam/slam_library.hpp) driven call by call as slam.cpp:250-319 drives it -- predict, then per
     marker update() (known ids) or associateLandmark() + update() (unknown ids: a synchronising call per marker) -- every
     call crossing the C ABI on its own.  Run as a child process (cpp/tests/api_rate) after the timed region."""
     import numpy as np
-    exe = os.path.join(ROOT, "shermbot-navigation_amd", "cpp", "tests", "api_rate")
+    exe = os.path.join(ROOT, "shermbot-navigation_amd", "cpp", "tests", exe_name)
     if not os.path.exists(exe):
-        return {"error": "cpp/tests/api_rate is not built"}
+        return {"error": "cpp/tests/%s is not built" % exe_name}
     res = {}
     ticks = min(tr.ticks, 256)
     for name, known in (("known_ids", 1), ("unknown_ids", 0)):
@@ -424,7 +424,7 @@ def main():
     blocks_cap = int(min(MAX_BLOCKS, max(MIN_BLOCKS, np.ceil(args.min_timed_ms / (K * STEP_MS_GUESS[args.workload] * (B / 1024.0 if args.workload == "batch" else 1.0))))))
     if args.blocks > 0:
         blocks_cap = args.blocks
-    ticks_total = W + K * (blocks_cap + 1)
+    ticks_total = W + K * (blocks_cap + 2)       # (+ the kernel-event pass, + the pass-on-its-own pass of a fused single-filter tick)
 
     # ---- synthetic input (seeded; Monte-Carlo replica r uses seed 12345 + r), made resident in HBM
     seed = 12345 if args.workload == "batch" else 12345 + rank      # the batch is ONE world split over the ranks
@@ -551,6 +551,24 @@ def main():
         bt.profile(True)
         bt.run(t_at, t_at + K)
         bt.sync()
+        t_at += K
+    fused_launch = None
+    if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1) and not (args.per_correction or args.no_pairing or args.group
+                                                                                                 or args.deferred or args.overlap):
+        # The default single-filter tick is ONE launch (k_tick_fused: predict || chain || strips || the rank-2m pass as workgroups of
+        # one grid), whose duration is the serial chain's.  The HBM-bound kernel's own figures come from K more steps of the same
+        # trace with the pass as a launch of its own (tick mode 4: k_tick_front + k_tick_rank -- the same arithmetic, the same bits).
+        fz_ms, fz_n = bt.profile_read(nh.K_TICK_CHAIN)
+        rk_ms, rk_n = bt.profile_read(nh.K_TICK_RANK)
+        if fz_n and not rk_n:
+            fused_launch = {"kernel": "k_tick_fused (predict || chain || strips || pass, csrc/ekf_fused.h)", "avg_launch_us": 1e3 * fz_ms / fz_n,
+                            "launches": fz_n}
+            bt.set_tick_mode(4)
+            bt.profile(True)
+            bt.run(t_at, t_at + K)
+            bt.sync()
+            t_at += K
+            bt.set_tick_mode(1)
     sweep_ms, sweep_n = bt.profile_read(nh.K_UPDATE)
     pair_ms, pair_n = bt.profile_read(nh.K_UPDATE2)
     pred_ms, pred_n = bt.profile_read(nh.K_PREDICT)
@@ -710,14 +728,24 @@ def main():
                                    "of this build (null when no record matches nuslam_build_info())"}
         if exact_pass:
             out["roofline"]["exact_pass_behind_it"] = exact_pass
+        if fused_launch:
+            fused_launch["whole_launch_GBps"] = min_bytes / (1e-6 * fused_launch["avg_launch_us"]) / 1e9
+            fused_launch["note"] = ("the timed region runs the tick as this ONE launch: the pass's tile loads run under the serial chain, its "
+                                    "k-steps follow the strips, its stores close the launch; roofline.achieved / frac above are k_tick_rank's, "
+                                    "measured in %d more steps with the pass as a launch of its own (tick mode 4: same arithmetic, same bits)" % K)
+            out["roofline"]["fused_launch"] = fused_launch
         # ... and the same bytes over the WHOLE tick (every kernel of it, launch gaps included): what the chip's HBM sees of a tick
         tick_s = dt_med / K
         out["roofline"]["whole_tick"] = {"bytes_per_step": min_bytes, "ms_per_step": 1e3 * tick_s, "GBps": min_bytes / tick_s / 1e9,
                                          "frac": min_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
                                          "note": "2*L^2*w*B / ms_per_step: the pass's bytes over the wall time of a whole tick"}
+        kernel_us_fused = fused_launch
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
+        if kernel_us_fused:
+            out["kernel_us"]["tick_fused"] = kernel_us_fused["avg_launch_us"]
+            out["kernel_us"]["note"] = "tick_fused: the one launch of the timed region; tick_chain (k_tick_front) / tick_rank: the two launches of tick mode 4"
         if apply_n or rank_n:
             out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / chain_n if chain_n else None,
                                      "tick_panels": 1e3 * panel_ms / panel_n if panel_n else None,

@@ -555,6 +555,9 @@ struct DaServe {
                              // workgroups meet: the meet, the drain in front of it and the next trip's top then run beside the host's turn
     int seq0;                // sequence number of the first command of this launch
     int timeout_ticks;       // 100 MHz ticks workgroup 0 waits for a command before it closes the round by itself
+    double* mirror;          // host (mapped, pinned), may be null: the state vector the round leaves, stored by the workgroups as they
+    long long* mtags;        // write it to the device's copy; mtags[workgroup] = mseq behind each workgroup's entries (TickTagged, ekf_tick.h)
+    long long mseq;
 };
 enum { DA_F_CORR = 1, DA_F_INIT = 2, DA_F_SCAN = 4, DA_F_END = 8, DA_F_ZOVR = 16, DA_F_CLEAR = 32, DA_F_PARK = 64 };
 constexpr long long kDaCmdMagic = 0x5a17c0de5a17c0dell;
@@ -1093,6 +1096,7 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
                     const double sx = nS[lane];
                     st_agent(&sn[t], sx);
                     if (last) v.s_out[(size_t)b * ld + t] = sx;
+                    if (SERVED && last && srv.mirror) st_sys(srv.mirror + t, sx);
                 }
             }
         } else if (wave == 2) {
@@ -1110,6 +1114,11 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
             }
         }
         DCK(6);
+        if (SERVED && last && srv.mirror && st >= 0) {                  // (uniform) this workgroup's share of the state is in the host's mirror
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) st_sys(srv.mtags + wg, srv.mseq);
+        }
         if (last) {
             // (SERVED: the END command has been carried out -- a round that parked has said so already)
             if (SERVED && wg == 0 && tid == 0 && (f_flags & DA_F_PARK) == 0) da_answer(srv, srv.seq0 + st + 1, 0, seen, status, 0);

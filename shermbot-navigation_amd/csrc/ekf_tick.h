@@ -480,7 +480,15 @@ struct TickTagged {
     long long* tagK;       // [B][2 kTickJ][ld][2]
     long long* tagV;
     int tag;               // this round's tag (never 0: the buffers start zeroed)
+    // the state vector the round leaves, mirrored into mapped pinned HOST memory as the strips form it (getStateVector() of the
+    // caller's loop, slam.cpp:184,250, then needs neither a stream synchronisation nor a device-to-host copy): every strip
+    // workgroup stores its entries (system scope), drains, and stamps mtags[workgroup] = mseq
+    double* mirror;        // null: no mirror
+    long long* mtags;
+    long long mseq;
 };
+__device__ inline void st_sys(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ inline void st_sys(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // { half, tag } words of a tagged strip element
 __device__ inline void st_tagged(long long* p, double x, int tag)
 {
@@ -1667,6 +1675,14 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         else loop(std::false_type{});
     }
     if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
+    if constexpr (TAGGED) {
+        if (tg.mirror) {                                                // (uniform)
+            if (role == 1 && owner) st_sys(tg.mirror + t, sv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) st_sys(tg.mtags + wg, tg.mseq);
+        }
+    }
     if (role == 1 && pm >= 0) SU[(size_t)b * NU + pm] = sv;
 }
 

@@ -12,6 +12,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -105,6 +106,12 @@ struct nuslam_batch {
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
     int fuse_pass = 1;         // 1: ... and the rank-2m pass over P as workgroups of that launch too (k_tick_fused, ekf_fused.h) in rounds
                                // the host can prove free of first sightings; 0: the pass as a launch of its own behind it (tick mode 4)
+    // the state vector mirrored into mapped pinned host memory by the kernels that produce it (fused ticks, served rounds): get_state
+    // then answers without a stream synchronisation and without a device-to-host copy
+    double* st_host = nullptr; long long* st_tags = nullptr;
+    long long st_seq = 0;      // the stamp of the last mirrored launch
+    int st_ntags = 0;          // ... and how many workgroups stamp
+    unsigned long long state_epoch = 1, mirror_epoch = 0;   // mirror valid <=> nothing has touched the state since that launch
     long long* tk_tagK = nullptr;   // [B][2 kTickJ][ld][2]: the K / V strips of a fused round as self-validating { half, tag } words
     long long* tk_tagV = nullptr;
     unsigned seq_tag = 0;      // the last round's tag (0 is never one)
@@ -175,6 +182,7 @@ struct nuslam_batch {
         int p_id = 0; bool p_init = false; double p_r = 0.0, p_phi = 0.0;
         bool z_valid = false; double z_r = 0.0, z_phi = 0.0;    // the marker the device scanned last (its correction's default z)
         bool clear_status = false;             // the latched status was returned to the caller: the next command clears it
+        long long mirror_seq = 0;              // the open round stamps the state mirror with this when it ends
         int timeout_us = 1000;                 // the device closes a round by itself when no command comes for this long
         bool used = false;                     // associateLandmark was called since the last predict: the caller's loop is slam.cpp's, and
                                                // the next predict() opens the next served round at once (predict kernel and round kernel
@@ -330,7 +338,7 @@ int do_predict(nuslam_batch* h, const TwistArg& tw)
                                    (T*)nullptr)));
     }
     if (rc) return rc;
-    h->sidx ^= 1;
+    h->sidx ^= 1; h->state_epoch++;
     h->cidx ^= 1;
     return NUSLAM_OK;
 }
@@ -388,7 +396,7 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
                                         total, h->J, (const T*)h->P(), h->dU, h->dV)));
         if (rcd) return rcd;
         h->J += 1;
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
         return NUSLAM_OK;
     }
@@ -413,7 +421,7 @@ int do_update(nuslam_batch* h, const ObsArg& o, int mode, int total)
     else { if (inl) LAUNCH_UPDATE(MODE_KNOWN, true); else LAUNCH_UPDATE(MODE_KNOWN, false); }
 #undef LAUNCH_UPDATE
     if (rc) return rc;
-    h->sidx ^= 1;
+    h->sidx ^= 1; h->state_epoch++;
     h->cidx ^= 1;
     h->pidx ^= 1;
     if (mode == MODE_DA) h->aslot ^= 1;
@@ -433,7 +441,7 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
     else
         DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_update2<T, 4>, grid, block, v, o1, o2, (const T*)h->P(), (T*)h->Palt())));
     if (rc) return rc;
-    h->sidx ^= 1;
+    h->sidx ^= 1; h->state_epoch++;
     h->cidx ^= 1;
     h->pidx ^= 1;
     return NUSLAM_OK;
@@ -460,7 +468,7 @@ int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, 
     int rc = NUSLAM_OK;
     DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_updatej<T, J>, grid, block, v, o, (const T*)h->P(), (T*)h->Palt())));
     if (rc) return rc;
-    h->sidx ^= 1;
+    h->sidx ^= 1; h->state_epoch++;
     h->cidx ^= 1;
     h->pidx ^= 1;
     return NUSLAM_OK;
@@ -477,6 +485,7 @@ bool tick_pipeline_pays(const nuslam_batch* h, int m)
 }
 
 int set_rank_attributes();
+int ensure_state_mirror(nuslam_batch* h);
 
 int ensure_tick_buffers(nuslam_batch* h)
 {
@@ -584,6 +593,7 @@ int launch_rank_t(nuslam_batch* h, const View& v, int J, const TickStep* plan, i
 }
 #define RANK_TILES(X)                                                                           \
     X(double, 4, 1, 1, 4) X(double, 1, 4, 4, 1) X(double, 2, 2, 2, 2) X(double, 2, 2, 1, 4)       \
+    X(double, 1, 2, 2, 2) X(double, 1, 1, 2, 2) X(double, 2, 1, 2, 2) X(double, 1, 2, 1, 4) X(double, 2, 3, 2, 2)   \
     X(float, 2, 2, 1, 4) X(float, 1, 4, 4, 1) X(float, 1, 4, 2, 2) X(float, 2, 1, 1, 4)
 int set_rank_attributes()
 {
@@ -603,7 +613,16 @@ int launch_rank(nuslam_batch* h, const View& v, int J, const TickStep* plan, int
         case 1: return launch_rank_t<double, 4, 1, 1, 4>(h, v, J, plan, check_init, sb);
         case 2: return launch_rank_t<double, 1, 4, 4, 1>(h, v, J, plan, check_init, sb);
         case 3: return launch_rank_t<double, 2, 2, 1, 4>(h, v, J, plan, check_init, sb);
-        default: return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init, sb);
+        // smaller workgroup tiles (a 403 x 403 matrix under 128 x 64 tiles is covered 1.41 times) and the fused launch's 128 x 96
+        case 4: return launch_rank_t<double, 1, 2, 2, 2>(h, v, J, plan, check_init, sb);     // 64 x 64
+        case 5: return launch_rank_t<double, 1, 1, 2, 2>(h, v, J, plan, check_init, sb);     // 64 x 32
+        case 6: return launch_rank_t<double, 2, 1, 2, 2>(h, v, J, plan, check_init, sb);     // 128 x 32
+        case 7: return launch_rank_t<double, 1, 2, 1, 4>(h, v, J, plan, check_init, sb);     // 32 x 128
+        case 8: return launch_rank_t<double, 2, 3, 2, 2>(h, v, J, plan, check_init, sb);     // 128 x 96
+        default:
+            // 128 x 64 tiles cover a 403 x 403 matrix (N = 200) 1.41 times, 64 x 64 tiles 1.24 times: 3 % faster there (profiles/r04/pass_tiles.txt)
+            if (h->L <= 600) return launch_rank_t<double, 1, 2, 2, 2>(h, v, J, plan, check_init, sb);
+            return launch_rank_t<double, 2, 2, 2, 2>(h, v, J, plan, check_init, sb);
         }
     }
     switch (h->rank_tile) {
@@ -779,7 +798,7 @@ int do_da_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const do
         }
         rc = launch_pass(h, v, o.J, h->tk_plan, false, true, whole(h));  // (association decides on the device whether a landmark is new)
         if (rc) return rc;
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
         h->pidx ^= 1;
     }
@@ -839,11 +858,18 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
                 if (h->seq_tag == 0u) h->seq_tag = 1u;
                 TickTagged tg;
                 tg.tagK = h->tk_tagK; tg.tagV = h->tk_tagV; tg.tag = (int)h->seq_tag;
+                tg.mirror = nullptr; tg.mtags = nullptr; tg.mseq = 0;
+                if (h->lazy.on && i0 + kTickJ >= m && strip_wgs <= 512 && ensure_state_mirror(h) == NUSLAM_OK) {
+                    // (the tick's last round: its strips leave the state the caller's next getStateVector() reads)
+                    h->st_seq += 1;
+                    tg.mirror = h->st_host; tg.mtags = h->st_tags; tg.mseq = h->st_seq;
+                }
                 int n_pass = 0;
                 DISPATCH_T(h, n_pass = FusedTile<T>::blocks(h->ld, h->L));
                 DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_fused<T>, dim3(1 + n_pred + strip_wgs + n_pass, 1), dim3(256), v, o, total,
                                            (T*)h->P(), (T*)h->Palt(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, tg, n_pred, strip_wgs, o.J, h->tk_sync + 2)));
                 if (rc) return rc;
+                if (tg.mirror) { h->st_ntags = strip_wgs; h->mirror_epoch = h->state_epoch + 1; }    // (+1: the flip below)
             } else {
                 DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_tick_front<T>, dim3(1 + n_pred + strip_wgs, h->B), dim3(256), v, o, total,
                                            (T*)h->P(), h->tk_plan, h->tk_K, h->tk_R, vbuf, pub, n_pred, h->tk_sync + 2)));
@@ -862,7 +888,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             rc = launch_strips_and_pass(h, v, o, h->tk_plan, false, may_init, [] { return (int)NUSLAM_OK; });
             if (rc) return rc;
         }
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
         h->pidx ^= 1;
     }
@@ -932,7 +958,7 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
                                           filt<T>(h->P(), h, sb), h->predict_bookkeeping, (T*)nullptr)));
         }
         if (rc) return rc;
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
     }
     const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);
@@ -968,7 +994,7 @@ int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& ba
             h->gpass_set[g] = true;
         }
         if (rc) return rc;
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
         h->pidx ^= 1;
     }
@@ -1074,6 +1100,15 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
     return NUSLAM_OK;
 }
 
+int ensure_state_mirror(nuslam_batch* h)
+{
+    if (h->st_host) return NUSLAM_OK;
+    HIPCHK(hipHostMalloc((void**)&h->st_host, sizeof(double) * (size_t)h->ld, hipHostMallocMapped));
+    HIPCHK(hipHostMalloc((void**)&h->st_tags, sizeof(long long) * 512, hipHostMallocMapped));
+    for (int i = 0; i < 512; ++i) h->st_tags[i] = 0;
+    return NUSLAM_OK;
+}
+
 // ---- the served round (unknown association driven call by call): host side of csrc/ekf_da.h "a round SERVED to the host"
 int get_seen(nuslam_batch* h, int b, int* seen);
 bool serve_usable(const nuslam_batch* h)
@@ -1102,6 +1137,12 @@ int serve_open(nuslam_batch* h)
     o.log_slot0 = -1;
     DaServe ds;
     ds.cmd = sv.mail; ds.ans = sv.mail + 8; ds.keys = sv.mail + 16; ds.seq0 = sv.seq + 1; ds.timeout_ticks = sv.timeout_us * 100;
+    ds.mirror = nullptr; ds.mtags = nullptr; ds.mseq = 0;
+    if (h->da.nwg <= 512 && ensure_state_mirror(h) == NUSLAM_OK) {
+        h->st_seq += 1;
+        ds.mirror = h->st_host; ds.mtags = h->st_tags; ds.mseq = h->st_seq;
+        sv.mirror_seq = h->st_seq;
+    }
     const View v = h->view();
     double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
     int rc = NUSLAM_OK;
@@ -1187,9 +1228,10 @@ int serve_close(nuslam_batch* h, int slots)
     const View v = h->view();
     int rc = launch_pass(h, v, slots, h->tk_plan, false, sv.any_init, whole(h));
     if (rc) return rc;
-    h->sidx ^= 1;
+    h->sidx ^= 1; h->state_epoch++;
     h->cidx ^= 1;
     h->pidx ^= 1;
+    if (sv.mirror_seq == h->st_seq && sv.mirror_seq != 0) { h->st_ntags = h->da.nwg; h->mirror_epoch = h->state_epoch; }
     if (sv.any_init) for (auto& t : h->touched) t = 0;     // (which landmarks: not tracked for served rounds -- drop the proof)
     return NUSLAM_OK;
 }
@@ -1245,7 +1287,7 @@ int serve_end(nuslam_batch* h)
     if (parked && sv.pend) {
         // the device had closed the round before this arrived: the correction goes through the per-call kernels
         const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
-        if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+        if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), (h->state_epoch++, h->view()), o, h->state[h->sidx]);
         if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
     }
     sv.pend = false;
@@ -1272,7 +1314,7 @@ int serve_associate(nuslam_batch* h, double r, double phi, int* id_out)
             // the round had closed itself (no call for srv.timeout_us): the pending correction through the per-call kernels, then a new round
             if (sv.pend) {
                 const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
-                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), (h->state_epoch++, h->view()), o, h->state[h->sidx]);
                 if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
                 sv.pend = false;
                 if (rc) return rc;
@@ -1303,7 +1345,7 @@ int serve_update(nuslam_batch* h, double r, double phi, int id, bool init)
             int rc = serve_roundtrip(h, f, sv.p_id, 0.0, 0.0, cr, cphi, nullptr, &st, &parked);
             if (!rc && parked) {
                 const ObsArg o = inline_obs(sv.p_r, sv.p_phi, sv.p_id, 0);
-                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+                if (sv.p_init) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), (h->state_epoch++, h->view()), o, h->state[h->sidx]);
                 if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
             }
             sv.pend = false;
@@ -1357,13 +1399,13 @@ int lazy_flush(nuslam_batch* h)
         if (z.has_predict) rc = do_predict(h, tw);
         for (int i = 0; i < m && !rc; ++i) {
             const ObsArg o = inline_obs(z.r[i], z.phi[i], z.id[i], 0);
-            if (z.init[i]) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), o, h->state[h->sidx]);
+            if (z.init[i]) rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), (h->state_epoch++, h->view()), o, h->state[h->sidx]);
             if (!rc) rc = do_update(h, o, MODE_FORCE, h->n);
             if (!rc) h->touched[z.id[i]] = 1;         // (B == 1: the landmark has been corrected)
         }
     }
     if (!rc && z.pend_init)                             // an initializeLandmark no update() followed
-        rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), h->view(), inline_obs(z.pi_r, z.pi_phi, z.pi_id, 0), h->state[h->sidx]);
+        rc = launch(h, -1, k_init_landmark, dim3(1), dim3(1), (h->state_epoch++, h->view()), inline_obs(z.pi_r, z.pi_phi, z.pi_id, 0), h->state[h->sidx]);
     return rc;
 }
 
@@ -1525,7 +1567,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             }
             rc = launch_pass(h, v, o.J, plan, more, may_init, whole(h));
             if (rc) return rc;
-            h->sidx ^= 1;
+            h->sidx ^= 1; h->state_epoch++;
             h->cidx ^= 1;
             h->pidx ^= 1;
             continue;
@@ -1544,7 +1586,7 @@ int run_overlapped(nuslam_batch* h, int t_begin, int t_end, int total)
             return launch(h, -1, k_tick_signal, dim3(1), dim3(64), cnt_next);
         });
         if (rc) return rc;
-        h->sidx ^= 1;
+        h->sidx ^= 1; h->state_epoch++;
         h->cidx ^= 1;
         h->pidx ^= 1;
     }
@@ -1563,6 +1605,8 @@ void free_batch(nuslam_batch* h)
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->srv.mail) (void)hipHostFree(h->srv.mail);
+    if (h->st_host) (void)hipHostFree(h->st_host);
+    if (h->st_tags) (void)hipHostFree(h->st_tags);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
                      h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_tagK, h->tk_tagV, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
@@ -1677,6 +1721,7 @@ int init_batch(nuslam_batch* h, const double* robot, const double* map, const do
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->sidx = 0; h->cidx = 0; h->pidx = 0; h->aslot = 0;
+    h->state_epoch++;
     h->host_seen.assign((size_t)h->B, 0); h->host_seen_valid = true;
     h->touched.assign((size_t)h->B * (h->n + 1), 0);
     for (int b = 0; b < h->B; ++b) { int zrc = zero_strips(h, b); if (zrc) return zrc; }
@@ -1729,6 +1774,24 @@ int get_state(nuslam_batch* h, int b, double* out, int len)
     if (!h || !out || b < 0 || b >= h->B || len < h->L) return NUSLAM_E_ARG;
     HIPCHK(hipSetDevice(h->device));
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
+    if (h->st_host && h->mirror_epoch == h->state_epoch && h->B == 1) {
+        // the launch that formed this state also wrote it into mapped host memory, workgroup by workgroup: wait for their stamps --
+        // no stream synchronisation (the pass over P may still be running), no device-to-host copy
+        volatile long long* tags = h->st_tags;
+        const auto t0 = std::chrono::steady_clock::now();
+        int got = 0;
+        for (unsigned spin = 1; got < h->st_ntags; ++spin) {
+            while (got < h->st_ntags && tags[got] == h->st_seq) ++got;
+            if (got == h->st_ntags) break;
+            __builtin_ia32_pause();
+            if ((spin & 0x3fff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+        }
+        if (got == h->st_ntags) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            memcpy(out, h->st_host, sizeof(double) * h->L);
+            return NUSLAM_OK;
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->state[h->sidx] + (size_t)b * h->ld, sizeof(double) * h->L, hipMemcpyDeviceToHost));
     return NUSLAM_OK;
@@ -1797,6 +1860,7 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     }
     int c[C_WORDS] = { seen, seen, 0, 0 };
     HIPCHK(hipMemcpy(h->ctrl[h->cidx] + (size_t)b * C_WORDS, c, sizeof(c), hipMemcpyHostToDevice));
+    h->state_epoch++;
     if (h->poisoned) {                                     // a restored filter is a valid one again -- the handle once ALL of them are
         if (h->needs_restore.size() != (size_t)h->B) h->needs_restore.assign((size_t)h->B, 1);
         h->needs_restore[b] = 0;
@@ -2343,7 +2407,7 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
 {
-    if (!h || variant < 0 || (variant > 2 && variant < 10) || variant > 13) return NUSLAM_E_ARG;
+    if (!h || variant < 0 || (variant > 2 && variant < 10) || variant > 18) return NUSLAM_E_ARG;
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
     if (variant >= 10) { h->pass_mode = 0; h->rank_tile = variant - 10; return NUSLAM_OK; }
     h->pass_mode = variant;
@@ -2610,6 +2674,7 @@ int nuslam_ekf_init_landmark(nuslam_ekf_t* h, double range, double bearing, int 
         return NUSLAM_OK;
     }
     View v = c->view();
+    c->state_epoch++;
     return launch(c, -1, k_init_landmark, dim3(1), dim3(1), v, inline_obs(range, bearing, id, 0), c->state[c->sidx]);
 }
 

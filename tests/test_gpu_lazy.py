@@ -276,3 +276,30 @@ def test_served_round_full_map_is_reported_from_inside_the_call(hip):
     assert e.value.code == hip.E_BOUNDS
     a.sync()
     assert a.status() == 0 and a.seen == n
+
+
+def test_state_getter_from_the_host_mirror_equals_the_device_copy(hip):
+    """getStateVector() at the top of the caller's loop (slam.cpp:184,250): the launch that forms a tick's state also writes it
+    into mapped host memory, workgroup by workgroup, and the getter waits for their stamps instead of synchronising the stream and
+    copying.  A clone copies the DEVICE buffers and reads them back the plain way: both must hold the same bits, tick after tick,
+    with known ids (the fused launch) and with associateLandmark in the loop (the served round)."""
+    n, m, T = 200, 16, 6
+    lm = synth.make_landmarks(n - 1)
+    tr = synth.make_wellposed_trace(n - 1, T, m, landmarks=lm, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    for known in (True, False):
+        f = hip.EKF(np.zeros(3), np.zeros(2 * n), Qs, R)
+        f.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+        for t in range(T):
+            r, phi = polar(hip, tr.mx[t], tr.my[t])
+            if known:
+                drive_like_the_node(f, tr.tw[t], r, phi, tr.ids[t], n, n - 1)
+            else:
+                drive_with_association(f, tr.tw[t], r, phi, n)
+            s = f.state                                                 # through the mirror
+            c = f.clone()
+            assert np.array_equal(s, c.state), "tick %d (%s ids)" % (t, "known" if known else "unknown")
+            c.close()
+        assert f.status() == 0
+        f.close()

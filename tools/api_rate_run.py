@@ -15,3 +15,4 @@ ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 tr = synth.make_wellposed_trace(n, ticks, m, seed=12345)
 bx, by, wid = synth.warmup_observations(tr.landmarks)
 print(json.dumps(bench.api_driven(n, m, tr, bx, by, wid, synth.Q_DEFAULT, synth.R_DEFAULT)))
+print(json.dumps(bench.api_driven(n, m, tr, bx, by, wid, synth.Q_DEFAULT, synth.R_DEFAULT, exe_name="node_loop_rate")))
