@@ -94,7 +94,7 @@ def parse():
                          "device every tick -- a GEMM micro-measurement on fully dense operands (MFMA loops on mostly-zero "
                          "operands hold a higher clock), not the reference's predict")
     ap.add_argument("--interleave", type=int, default=None, help="nuslam_batch_set_interleave: groups of filters on streams of their own "
-                                                                 "(batch workload; default: the library's choice, 2 for large batches)")
+                                                                 "(batch workload; default: the library's, 1 = off: measured neutral)")
     ap.add_argument("--parity-ticks", type=int, default=40, help="ticks of the same-run parity leg (through nuslam_batch_run)")
     ap.add_argument("--no-api", action="store_true", help="skip the api_driven leg (the C++ class driven call by call)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")

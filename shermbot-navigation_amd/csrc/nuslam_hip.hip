@@ -97,7 +97,7 @@ struct nuslam_batch {
     unsigned seq_pub = 0, seq_gather = 0, seq_pred = 0;   // (sequence words: they wrap, the device compares wrapped differences)
     // Interleaved groups (nuslam_batch_set_interleave): a batch's known-id ticks run as G independent groups of filters, each on
     // a stream of its own, so that one group's HBM-bound pass over P overlaps another group's latency- / VALU-bound chain and
-    // strips.  Same kernels on the same per-filter data: same bits.  -1: the library picks (2 for large batches).
+    // strips.  Same kernels on the same per-filter data: same bits.  -1 (default): 1, i.e. off -- measured neutral (include/nuslam_hip.h).
     int groups = -1;
     hipStream_t gstream[4] = { nullptr, nullptr, nullptr, nullptr };
     hipEvent_t gev[4] = { nullptr, nullptr, nullptr, nullptr }, gev0 = nullptr;

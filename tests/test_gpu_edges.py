@@ -132,3 +132,53 @@ def test_many_markers_per_tick_and_repeated_ids(hip):
     o.tick(tw=tr.tw[0], mx=mx, my=my, known_ids=kid)
     g.tick(tr.tw[0], mx, my, known_ids=kid, want_ids=False)
     assert entry_rel_err(g.state, o.state) < 1e-9 and entry_rel_err(g.cov, o.cov) < 1e-8
+
+
+def test_poisoned_batch_comes_back_only_when_every_filter_was_restored(hip):
+    """An expired device-side wait (NUSLAM_E_SYNC) poisons the whole handle: the run went on from a hand-off that never arrived.
+    restore() of ONE filter of a batch must not re-admit the others (they still hold what the code itself declares invalid)."""
+    B, n, m, T = 3, 12, 5, 4
+    tr = synth.make_trace(n, T, m)
+    bt = hip.Batch(B, n, synth.Q_DEFAULT, synth.R_DEFAULT)
+    bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+    bt.run(0, 2)
+    snaps = [(bt.state(b), bt.cov(b), bt.seen(b)) for b in range(B)]
+    bt.inject_fault(1)                                                  # as if a hand-off between workgroups had expired
+    assert bt.status()[1] == hip.E_SYNC
+    with pytest.raises(hip.NuslamError) as e:
+        bt.run(2, 3)
+    assert e.value.code == hip.E_SYNC
+    bt.status(clear=True)
+    bt.restore(0, *snaps[0])
+    with pytest.raises(hip.NuslamError) as e:                           # filters 1 and 2 are still what the failed run left
+        bt.run(2, 3)
+    assert e.value.code == hip.E_SYNC
+    bt.restore(1, *snaps[1])
+    bt.restore(2, *snaps[2])
+    bt.run(2, T)                                                        # every filter restored: the handle ticks again
+    assert bt.status() == (-1, 0)
+    ref = hip.Batch(B, n, synth.Q_DEFAULT, synth.R_DEFAULT)
+    ref.load_trace(tr.tw[:, :2], tr.mx, tr.my, tr.ids, bcast=True)
+    ref.run(0, T)
+    for b in range(B):
+        assert np.array_equal(bt.state(b), ref.state(b)) and np.array_equal(bt.cov(b), ref.cov(b))
+
+
+def test_restore_clears_what_a_diverged_run_left_in_the_strips(hip):
+    """The rank-2m pass reads all 32 factor rows of the K / V strips every round and masks the unused ones by multiplication: a NaN a
+    diverged run left in a slot the next round does not rewrite (a skipped marker, fewer markers than a round) would spread over all of
+    P (0 * NaN).  restore() re-zeroes the filter's strips."""
+    n, m = 40, 16
+    tr = synth.make_wellposed_trace(n, 3, m) if False else synth.make_trace(n, 3, m)
+    f = hip.EKF(np.zeros(3), np.zeros(2 * n), synth.Q_DEFAULT, synth.R_DEFAULT)
+    f.as_batch().set_tick_mode(4)                                       # the pass as k_tick_rank, a launch of its own
+    bx, by, wid = synth.warmup_observations(tr.landmarks)
+    f.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)
+    f.tick(tr.tw[0], tr.mx[0], tr.my[0], known_ids=tr.ids[0], want_ids=False)
+    snap = f.snapshot()
+    f.as_batch().inject_fault(2)                                        # NaN in every strip slot
+    f.restore(*snap)
+    ids = tr.ids[1].copy()
+    ids[3] = -1                                                         # a slot the round leaves unwritten
+    f.tick(tr.tw[1], tr.mx[1][:10], tr.my[1][:10], known_ids=ids[:10], want_ids=False)      # and only ten markers of sixteen
+    assert np.isfinite(f.cov).all() and np.isfinite(f.state).all() and f.status() == 0
