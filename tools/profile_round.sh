@@ -4,7 +4,7 @@
 # Everything lands in gpurun_out/<round>/; copy what is to be judged into profiles/<round>/ afterwards.
 # rocprofv3: the program itself after `--`, counters in their own passes with --kernel-trace only.
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$ROUND
 mkdir -p "$OUT"
@@ -16,38 +16,37 @@ step() { echo "== $*" | tee -a "$OUT/progress.log"; }
 
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
 step bench lines
-timeout -k 10 300 $B > "$OUT/bench_ekf1000.json" 2> "$OUT/bench_ekf1000.err" || exit 1
-timeout -k 10 200 $B --tick-mode 3 --cpu-seconds 0 > "$OUT/bench_ekf1000_two_launches.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 400 $B > "$OUT/bench_ekf1000.json" 2> "$OUT/bench_ekf1000.err" || exit 1
+timeout -k 10 200 $B --tick-mode 4 --cpu-seconds 0 > "$OUT/bench_ekf1000_pass_as_second_launch.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --tick-mode 3 --cpu-seconds 0 > "$OUT/bench_ekf1000_three_launches.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --pass-variant 2 --tick-mode 3 --no-overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_one_stream.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 200 $B --pass-variant 1 --tick-mode 3 --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_overlapped.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 200 $B --tick-mode 3 --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_rank_overlapped.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 200 $B --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_streamed_overlap.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --tick-mode 4 --overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_streamed_overlap.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --per-correction --cpu-seconds 0 > "$OUT/bench_ekf1000_pairs.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --no-pairing --cpu-seconds 0 > "$OUT/bench_ekf1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 > "$OUT/bench_batch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 --pass-variant 1 > "$OUT/bench_batch_exact_chain.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 > "$OUT/bench_da1000.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --pass-variant 1 > "$OUT/bench_da1000_exact_chain.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 2 > "$OUT/bench_da1000_launch_per_marker.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 400 $B --workload da1000 --steps 100 --warmup 10 > "$OUT/bench_da1000.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 2 --cpu-seconds 0 > "$OUT/bench_da1000_launch_per_marker.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload ekf5000 > "$OUT/bench_ekf5000.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 300 $B --workload ekf5000 --dense-random-f > "$OUT/bench_ekf5000_dense_random_f.json" 2>> "$OUT/bench.err" || exit 1
-for v in 10 11 12 13; do
-    timeout -k 10 200 $B --tick-mode 3 --no-overlap --pass-variant $v --cpu-seconds 0 > "$OUT/tile_ekf1000_v$v.json" 2>> "$OUT/bench.err"
-    timeout -k 10 300 $B --workload batch --steps 30 --warmup 5 --pass-variant $v > "$OUT/tile_batch_v$v.json" 2>> "$OUT/bench.err"
-    timeout -k 10 300 $B --workload ekf5000 --pass-variant $v --steps 3 --warmup 1 > "$OUT/tile_ekf5000_v$v.json" 2>> "$OUT/bench.err"
+timeout -k 10 300 python3 $ROOT/tools/api_rate_run.py 256 > "$OUT/api_rates.json" 2>> "$OUT/bench.err" || exit 1
+for v in 10 11 12 13 14 15 16 18; do
+    timeout -k 10 200 $B --tick-mode 4 --pass-variant $v --cpu-seconds 0 --min-timed-ms 300 > "$OUT/tile_ekf1000_v$v.json" 2>> "$OUT/bench.err"
+    timeout -k 10 300 $B --workload batch --steps 20 --warmup 5 --pass-variant $v --min-timed-ms 300 > "$OUT/tile_batch_v$v.json" 2>> "$OUT/bench.err"
+    [ $v -le 13 ] && timeout -k 10 300 $B --workload ekf5000 --pass-variant $v --steps 3 --warmup 1 > "$OUT/tile_ekf5000_v$v.json" 2>> "$OUT/bench.err"
 done
 python3 - "$OUT" > "$OUT/pass_tiles.txt" <<'PY'
 import glob, json, os, sys
 out = sys.argv[1]
 print("the rank-2m pass (k_tick_rank), tile shape <RB, CB, WR, WC> per nuslam_batch_set_pass_variant(10 + k): launch duration (HIP events), fraction of 8 TB/s")
-names = {"f64": ["<2,2,2,2>", "<4,1,1,4>", "<1,4,4,1>", "<2,2,1,4>"], "f32": ["<2,1,1,4>", "<2,2,1,4>", "<1,4,4,1>", "<1,4,2,2>"]}
+names = {"f64": {10: "<2,2,2,2> 128x64 (N=1000 default)", 11: "<4,1,1,4>", 12: "<1,4,4,1>", 13: "<2,2,1,4>", 14: "<1,2,2,2> 64x64 (default for L <= 600)", 15: "<1,1,2,2> 64x32", 16: "<2,1,2,2> 128x32", 18: "<2,3,2,2> 128x96"},
+         "f32": {10: "<2,1,1,4>", 11: "<2,2,1,4>", 12: "<1,4,4,1>", 13: "<1,4,2,2>"}}
 for wl, dt in (("ekf1000", "f64"), ("batch", "f64"), ("ekf5000", "f32")):
-    for k in range(4):
+    for k in [v - 10 for v in sorted(names[dt])]:
         f = os.path.join(out, "tile_%s_v%d.json" % (wl, 10 + k))
         try:
             d = json.loads(open(f).read().strip().splitlines()[-1])
             r = d.get("roofline_hbm_kernel") or d["roofline"]
-            print("%-8s %s tile %d %-10s %9.1f us  %.3f of HBM peak   (%.4g updates/s)" % (wl, dt, k, names[dt][k], r["avg_launch_us"], r["frac"], d["value"]))
+            print("%-8s %s tile %d %-36s %9.1f us  %.3f of HBM peak   (%.4g updates/s)" % (wl, dt, k, names[dt][10 + k], r["avg_launch_us"], r["frac"], d["value"]))
         except Exception as e:
             print("%-8s tile %d: no line (%s)" % (wl, k, e))
 PY
@@ -69,7 +68,7 @@ stats() {   # name, bench args...
     rm -rf "$OUT/prof_$name"
 }
 stats ekf1000 --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 || exit 1
-stats ekf1000_two_launches --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 3 || exit 1
+stats ekf1000_pass_as_second_launch --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 4 || exit 1
 stats batch --workload batch --steps 20 --warmup 3 --blocks 2 --cpu-seconds 0 || exit 1
 stats da1000 --workload da1000 --steps 50 --warmup 5 --blocks 2 --cpu-seconds 0 || exit 1
 stats ekf5000 --workload ekf5000 --cpu-seconds 0 || exit 1
@@ -85,8 +84,11 @@ pmc() {     # name, counter, bench args...
 PM="--steps 40 --warmup 10 --blocks 1 --cpu-seconds 0"
 pmc ekf1000 FETCH_SIZE $PM || exit 1
 pmc ekf1000 WRITE_SIZE $PM || exit 1
+# (the default run launches k_tick_fused in its timed steps and k_tick_rank in the extra tick-mode-4 block of the event pass)
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_pmc_hbm_traffic.json" \
-    "k_tick_rank<double" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
+    "k_tick_rank<double" 40 2003 8 1 >> "$OUT/progress.log" 2>&1
+python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_fused_pmc_hbm_traffic.json" \
+    "k_tick_fused<double" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
 PB="--workload batch --steps 6 --warmup 2 --blocks 1 --cpu-seconds 0"
 pmc batch FETCH_SIZE $PB || exit 1
 pmc batch WRITE_SIZE $PB || exit 1
