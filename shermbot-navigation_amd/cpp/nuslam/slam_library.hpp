@@ -10,7 +10,15 @@
 //     per change) and stay valid until the next mutating call -- the lifetime the reference's member
 //     references have;
 //   - failures the reference surfaces as Armadillo exceptions keep their type: an out-of-range landmark index
-//     -> std::logic_error, a singular innovation covariance -> std::runtime_error.
+//     -> std::logic_error, a singular innovation covariance -> std::runtime_error;
+//   - LAZY TICKS (include/nuslam_hip.h, nuslam_ekf_set_lazy; default on): predict() / initializeLandmark() / update() are
+//     recorded by the library and reach the device as ONE tick -- predict, the serial chain, the strips and the one pass over
+//     the covariance in a single launch -- at the next predict(), getter, associateLandmark(), copy, sync() or destruction, so
+//     the loop of nuslam/src/slam.cpp:250-319, unchanged, runs at the rate of the one-call tick() extension.
+//     associateLandmark() is one command to a resident round kernel (a mailbox in mapped host memory), getSeenLandmarks()
+//     the library's host mirror, getStateVector() mapped host memory the kernels write.  A bad landmark id is still thrown by
+//     the call itself; a device-side failure (singular innovation covariance) surfaces at the next synchronising call.
+//     setLazy(false) restores one kernel launch -- one pass over the covariance -- per call.
 //
 // Vector / matrix types: arma::colvec / arma::mat when <armadillo> is available (the ROS build), otherwise the
 // two small column-major value types below, which provide just what this interface touches.
@@ -163,7 +171,7 @@ namespace slam_library
             touched(); o.touched();
         }
 
-        /// prediction step (slam_library.cpp:65-148); enqueue-and-return
+        /// prediction step (slam_library.cpp:65-148); recorded: opens the next tick (what was recorded before goes to the device)
         void predict(const Twist2D& tw)
         {
             require();
@@ -208,7 +216,7 @@ namespace slam_library
             touched();
         }
 
-        /// measurement update for landmark id (slam_library.cpp:263-282; the twist is unused, as in the reference)
+        /// measurement update for landmark id (slam_library.cpp:263-282; the twist is unused, as in the reference); recorded
         void update(const Twist2D& tw, colvec z_id, int id)
         {
             (void)tw;
@@ -276,10 +284,18 @@ namespace slam_library
             return seen_landmarks;
         }
 
-        /// wait for everything enqueued so far; surfaces latched device-side failures as exceptions
+        /// apply what was recorded, wait for everything enqueued so far; surfaces latched device-side failures as exceptions
         void sync() const
         {
             if (h_) detail::check(nuslam_ekf_sync(h_), "sync");
+        }
+
+        /// lazy ticks on (default) / off: see the header comment
+        void setLazy(bool on)
+        {
+            require();
+            detail::check(nuslam_ekf_set_lazy(h_, on ? 1 : 0), "setLazy");
+            touched();
         }
 
         /// checkpoint restore: overwrite (state, covariance, seen)
