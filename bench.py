@@ -272,9 +272,10 @@ def api_driven(n, m, tr, bx, by, wid, Q, R, exe_name="api_rate"):
             res[name] = json.loads(p.stdout.strip().splitlines()[-1]) if p.stdout.strip() else {"error": p.stderr[-300:]}
         except Exception as ex:
             res[name] = {"error": str(ex)[:300]}
-    res["note"] = ("slam_library::ExtendedKalman per call through the C ABI (predict + per marker update; unknown ids: "
-                   "associateLandmark, which returns the id to the host, in front of each) -- the drop-in rate; `value` is the "
-                   "resident-trace entry point nuslam_batch_run, which keeps the whole loop body on the device")
+    res["note"] = ("slam_library::ExtendedKalman per call through the C ABI, the unchanged loop of slam.cpp:250-319 (predict + per marker "
+                   "update; unknown ids: associateLandmark, which returns the id to the host, in front of each) -- the drop-in rate.  The "
+                   "library records the calls and applies them tick by tick (lazy ticks: k_tick_fused; a round served to the host through "
+                   "a mailbox in mapped memory for associateLandmark); `value` is the resident-trace entry point nuslam_batch_run")
     return res
 
 
@@ -837,7 +838,12 @@ def main():
                          "rel_frobenius_cov": float(np.linalg.norm(gP - oP) / np.linalg.norm(oP)),
                          "seen_equal": bool(g2.seen == os2.seen), "tolerance": 1e-6}
         if not args.no_api:
-            out["api_driven"] = api_driven(n, m, ptr, bx, by, wid, Q, R)
+            atr = synth.make_wellposed_trace(n, 256, m, seed=12345)
+            out["api_driven"] = api_driven(n, m, atr, bx, by, wid, Q, R)
+            # ... and with what the node does at the top of every iteration (slam.cpp:184,250-251: getStateVector twice, getSeenLandmarks)
+            nl = api_driven(n, m, atr, bx, by, wid, Q, R, exe_name="node_loop_rate")
+            out["api_driven"]["with_the_nodes_loop_top"] = {k: v for k, v in nl.items() if k != "note"}
+            out["api_driven"]["ticks"] = 256
     if args.workload == "da1000" and world == 1 and args.cpu_seconds > 0:
         out["parity"] = da_parity(nh, args, n, m, Q, R, dtype, dev, seed)
     print(json.dumps(out))

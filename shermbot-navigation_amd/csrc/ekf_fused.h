@@ -58,6 +58,9 @@ __device__ inline void tick_pass_role(const int b, const int idx, View v, const 
     const int tr = (k / tiles_c) * 8 + x, tc = k % tiles_c;
     if (tr >= tiles_r) return;
     const int row_w0 = tr * TL::WROWS + wr * RB * RG, col_w0 = tc * TL::WCOLS + wc * CB * 16;
+#if defined(NUSLAM_FUSED_BISECT) && NUSLAM_FUSED_BISECT == 1
+    return;                                                             // (measurement builds only: what the chain costs beside IDLE pass workgroups)
+#endif
     const T* Pb = Pin + (size_t)b * v.p_stride;
     const TickStep* pl = plan + (size_t)b * kTickJ;
 
@@ -125,7 +128,11 @@ __device__ inline void tick_pass_role(const int b, const int idx, View v, const 
     // the chain's own store acknowledgements ~0.5 us per correction
     const long long* probe0 = tV + (size_t)(tc * TL::WCOLS) * 2;
     const int ksl = (J - 1) >> 1;                                       // the last k-step that holds a correction
+#if defined(NUSLAM_FUSED_BISECT) && NUSLAM_FUSED_BISECT == 2
+    const int units = 0;                                                // (measurement builds only: tile loads and stores, no k-steps)
+#else
     const int units = ksl + 1;
+#endif
 #pragma unroll 1
     for (int u = 0; u < units; ++u) {
         const int ks = u;
