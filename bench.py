@@ -93,15 +93,12 @@ def parse():
                     help="ekf5000: propagate with a fixed dense random Jacobian instead of the reference's A = I + B formed on the "
                          "device every tick -- a GEMM micro-measurement on fully dense operands (MFMA loops on mostly-zero "
                          "operands hold a higher clock), not the reference's predict")
-    ap.add_argument("--interleave", type=int, default=None, help="nuslam_batch_set_interleave: groups of filters on streams of their own "
-                                                                 "(batch workload; default: the library's, 1 = off: measured neutral)")
     ap.add_argument("--parity-ticks", type=int, default=40, help="ticks of the same-run parity leg (through nuslam_batch_run)")
     ap.add_argument("--no-api", action="store_true", help="skip the api_driven leg (the C++ class driven call by call)")
     ap.add_argument("--no-overlap", action="store_true", help="tick pipeline on ONE stream (no chain running ahead)")
     ap.add_argument("--overlap", action="store_true", help="force the chain of tick t+1 onto a second stream (nuslam_batch_set_overlap; default: on for one filter, off for batches)")
     ap.add_argument("--per-correction", action="store_true",
                     help="round-1 path: one pass over P per correction / pair instead of the tick pipeline (same bits)")
-    ap.add_argument("--group", type=int, default=0, help="corrections per pass over P: 2 or 4 (0 = library default)")
     ap.add_argument("--min-timed-ms", type=float, default=None, help="the timed blocks add up to at least this (default per workload: MIN_TIMED_MS)")
     ap.add_argument("--blocks", type=int, default=0, help="run exactly this many timed K-step blocks (0: until --min-timed-ms)")
     ap.add_argument("--events-in-timed-region", action="store_true",
@@ -452,7 +449,7 @@ def main():
     if B == 1 and args.workload != "batch":
         ekf = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
         bt = ekf.as_batch()
-        if args.per_correction or args.no_pairing or args.group or args.tick_mode == 0:
+        if args.per_correction or args.no_pairing or args.tick_mode == 0:
             bt.set_tick_mode(0)        # (before the map is initialised: pairing needs the host's mirror of `seen`, which
                                        # only the per-correction path maintains)
         ekf.tick(np.zeros(3), bx, by, known_ids=wid, want_ids=False)     # initialise the whole map (untimed)
@@ -501,7 +498,7 @@ def main():
         bt.load_trace(tr.tw[:, :2], tr.mx, tr.my, ids, bcast=True)
     if args.deferred:
         bt.set_deferred(True)
-    if args.per_correction or args.no_pairing or args.group:
+    if args.per_correction or args.no_pairing:
         bt.set_tick_mode(0)
     elif args.tick_pipeline:
         bt.set_tick_mode(1)
@@ -511,16 +508,12 @@ def main():
         bt.set_pass_variant(1)
     if args.pass_variant is not None:
         bt.set_pass_variant(args.pass_variant)
-    if args.interleave is not None:
-        bt.set_interleave(args.interleave)
     if args.no_overlap:
         bt.set_overlap(False)
     if args.overlap:
         bt.set_overlap(True)
     if args.no_pairing:
         bt.set_pairing(False)
-    elif args.group:
-        bt.set_pairing(args.group)
 
     def barrier():
         if world > 1:
@@ -554,7 +547,7 @@ def main():
         bt.sync()
         t_at += K
     fused_launch = None
-    if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1) and not (args.per_correction or args.no_pairing or args.group
+    if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1) and not (args.per_correction or args.no_pairing
                                                                                                  or args.deferred or args.overlap):
         # The default single-filter tick is ONE launch (k_tick_fused: predict || chain || strips || the rank-2m pass as workgroups of
         # one grid), whose duration is the serial chain's.  The HBM-bound kernel's own figures come from K more steps of the same
@@ -804,7 +797,7 @@ def main():
         g2 = nh.EKF(np.zeros(3), np.zeros(2 * n), Q, R, dtype=dtype, device=dev)
         g2.restore(*warm_state)
         b2 = g2.as_batch()
-        if args.per_correction or args.no_pairing or args.group:
+        if args.per_correction or args.no_pairing:
             b2.set_tick_mode(0)
         elif args.tick_pipeline:
             b2.set_tick_mode(1)
@@ -820,8 +813,6 @@ def main():
             b2.set_overlap(True)
         if args.no_pairing:
             b2.set_pairing(False)
-        elif args.group:
-            b2.set_pairing(args.group)
         b2.load_trace(ptr.tw[:pt, :2], ptr.mx[:pt], ptr.my[:pt], ptr.ids[:pt], bcast=True)
         b2.run(0, pt)
         bad2, st2 = b2.status()

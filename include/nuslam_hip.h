@@ -31,7 +31,8 @@ extern "C" {
  *    _CAPACITY; nuslam_batch_set_pass_variant selects between the rank-2m pass and the exact chain; NUSLAM_K_TICK_RANK */
 /* 3: nuslam_ekf_predict / _init_landmark / _update of a single filter are RECORDED and applied tick by tick (see "Lazy ticks"
  *    below; nuslam_ekf_set_lazy); nuslam_ekf_tick_ex; nuslam_batch_inject_fault; a poisoned handle (NUSLAM_E_SYNC) comes back only
- *    when every filter has been restored.  (Also since 2, not listed then: nuslam_sim_params grew by `fov` and `min_range` --
+ *    when every filter has been restored; RETIRED: nuslam_batch_set_interleave (groups of filters on streams of their own: measured
+ *    neutral) and the four-corrections-per-pass kernel behind nuslam_batch_set_pairing(h, 4) (slower than pairs).  (Also since 2, not listed then: nuslam_sim_params grew by `fov` and `min_range` --
  *    a caller compiled against the version-1 struct must be rebuilt.) */
 #define NUSLAM_HIP_ABI_VERSION 3
 
@@ -213,8 +214,7 @@ int nuslam_ekf_as_batch(nuslam_ekf_t* h, nuslam_batch_t** out); /* borrowed; do 
 int nuslam_batch_set_deferred(nuslam_batch_t* h, int enable);
 /* Pairing (default on): inside a tick with known ids, consecutive corrections of already-initialised landmarks are
  * applied two at a time by one pass over the covariance (k_update2) -- same arithmetic, same bits, half the HBM
- * bytes per correction.  enable = 0 forces one k_update launch per correction; enable = 4 selects the experimental
- * four-per-pass kernel (k_updatej, also bit-identical, currently slower than pairs). */
+ * bytes per correction.  enable = 0 forces one k_update launch per correction. */
 int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable);
 int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
 /* How a known-id tick (nuslam_ekf_tick with known_ids, nuslam_batch_run on a trace with ids) applies its corrections.
@@ -243,12 +243,6 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
  * rank-2m pass (one stream is the faster order there), on for one filter / off for batches with the exact chain.
  * Should a hand-off expire all the same (NUSLAM_E_SYNC), the handle refuses further ticks until it is restored. */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
-/* nuslam_batch_run on a known-id trace, large batches: the filters are dealt into `groups` contiguous groups (1..4), each
- * running its ticks on a stream of its own, so that one group's HBM-bound pass over the covariance overlaps another group's
- * latency- and VALU-bound chain and strips (independent filters: nothing is exchanged).  Same kernels on the same
- * per-filter data: same bits for every group count.  Default 1 (off): measured at 1024 x N = 200 the groups' kernels only take
- * turns at the same resources (16.0 -> 16.3 M updates/s); kept as a measurement switch. */
-int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups);
 /* How a tick pipeline's ONE pass over the covariance applies the round's corrections.
  *   0 (default)  as a rank-2m update on the matrix cores: update()'s P <- (I - K H) P (slam_library.cpp:279) re-associated
  *                as P - K (H P), all corrections of the round in one v_mfma_f64 accumulation per tile -- 2 FMAs per element

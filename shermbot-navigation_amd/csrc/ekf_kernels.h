@@ -348,5 +348,4 @@ __global__ __launch_bounds__(256) void k_stats(View v, const double* __restrict_
 #include "ekf_rank.h"
 #include "ekf_fused.h"
 #include "ekf_da.h"
-#include "ekf_updatej.h"
 #include "ekf_deferred.h"

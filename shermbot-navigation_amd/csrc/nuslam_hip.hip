@@ -95,14 +95,6 @@ struct nuslam_batch {
     bool tk_ready = false;     // every buffer of the tick pipeline allocated and initialised (ensure_tick_buffers)
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
     unsigned seq_pub = 0, seq_gather = 0, seq_pred = 0;   // (sequence words: they wrap, the device compares wrapped differences)
-    // Interleaved groups (nuslam_batch_set_interleave): a batch's known-id ticks run as G independent groups of filters, each on
-    // a stream of its own, so that one group's HBM-bound pass over P overlaps another group's latency- / VALU-bound chain and
-    // strips.  Same kernels on the same per-filter data: same bits.  -1 (default): 1, i.e. off -- measured neutral (include/nuslam_hip.h).
-    int groups = -1;
-    hipStream_t gstream[4] = { nullptr, nullptr, nullptr, nullptr };
-    hipEvent_t gev[4] = { nullptr, nullptr, nullptr, nullptr }, gev0 = nullptr;
-    hipEvent_t gpass[4] = { nullptr, nullptr, nullptr, nullptr };   // group g's last pass over P is done
-    bool gpass_set[4] = { false, false, false, false };
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
     int fuse_pass = 1;         // 1: ... and the rank-2m pass over P as workgroups of that launch too (k_tick_fused, ekf_fused.h) in rounds
                                // the host can prove free of first sightings; 0: the pass as a launch of its own behind it (tick mode 4)
@@ -147,8 +139,7 @@ struct nuslam_batch {
     int seq_chain = 0, seq_next = 0;                   // the counters' values after everything enqueued so far
     hipEvent_t ov_start = nullptr;
     std::vector<hipEvent_t> ov_events;
-    bool pairing = true;       // k_update2 / k_updatej for consecutive plain corrections of a known-id tick
-    int group = 2;             // corrections per pass: 2 = k_update2, 4 = k_updatej<4> (3 = k_updatej<2>, for A/B only)
+    bool pairing = true;       // k_update2 for consecutive plain corrections of a known-id tick
     std::vector<int> host_seen;   // host mirror of every filter's `seen`; valid while only known-id calls were made
     bool host_seen_valid = true;
     bool deferred = false;
@@ -447,33 +438,6 @@ int do_update2(nuslam_batch* h, const ObsArg& o1, const ObsArg& o2)
     return NUSLAM_OK;
 }
 
-// J consecutive plain corrections in one pass (k_updatej); markers i .. i+J-1 of the tick
-template <int J>
-int do_updatej(nuslam_batch* h, const ObsArg& base, int i, const int* host_ids, const double* host_mx, const double* host_my)
-{
-    View v = h->view();
-    ObsJ o;
-    o.a = host_mx ? nullptr : base.a; o.b = host_mx ? nullptr : base.b;
-    o.stride = base.stride; o.off = base.off + i;
-    for (int s = 0; s < 4; ++s) {
-        o.a0[s] = (host_mx && s < J) ? host_mx[i + s] : 0.0;
-        o.b0[s] = (host_my && s < J) ? host_my[i + s] : 0.0;
-        o.id[s] = s < J ? host_ids[i + s] : 1;
-    }
-    o.cartesian = base.cartesian;
-    o.log_slot = h->id_log ? i : -1;
-    const int vec = 16 / (int)h->esize();
-    const int strips = (h->L + kSweepCW - 1) / kSweepCW;
-    dim3 grid((h->ld + 64 * vec - 1) / (64 * vec), (strips + 3) / 4, h->B), block(256);
-    int rc = NUSLAM_OK;
-    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_UPDATE2, k_updatej<T, J>, grid, block, v, o, (const T*)h->P(), (T*)h->Palt())));
-    if (rc) return rc;
-    h->sidx ^= 1; h->state_epoch++;
-    h->cidx ^= 1;
-    h->pidx ^= 1;
-    return NUSLAM_OK;
-}
-
 // The tick pipeline moves P once per tick instead of once per pair of corrections, at the price of a serial chain
 // (~2.4 us per correction, one workgroup per filter) and the strip kernel.  With many filters those run side by side and
 // the pass over P dominates (measured 2x at 1024 x N = 200); for ONE filter the chain is exposed and the gain is
@@ -558,7 +522,7 @@ TickObs make_tick_obs(const nuslam_batch* h, const ObsArg& base, int i0, int m, 
     return o;
 }
 
-// A contiguous range of the handle's filters and the stream its launches go to (interleaved groups); default: all of them
+// A contiguous range of the handle's filters and the stream its launches go to; default: all of them
 struct Sub {
     int g0, Bg;
     hipStream_t st;
@@ -895,113 +859,6 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
     return NUSLAM_OK;
 }
 
-// ---- interleaved groups
-int group_count(const nuslam_batch* h)
-{
-    int g = h->groups < 0 ? 1 : h->groups;
-    if (g > 4) g = 4;
-    if (g > h->B) g = h->B;
-    return g < 1 ? 1 : g;
-}
-Sub group_of(nuslam_batch* h, int g, int G)
-{
-    const int g0 = (int)((long long)h->B * g / G), g1 = (int)((long long)h->B * (g + 1) / G);
-    return Sub{ g0, g1 - g0, g == 0 ? h->stream : h->gstream[g] };
-}
-int ensure_groups(nuslam_batch* h, int G)
-{
-    for (int g = 1; g < G; ++g)
-        if (!h->gstream[g]) {
-            HIPCHK(hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
-        }
-    if (!h->gev0) HIPCHK(hipEventCreateWithFlags(&h->gev0, hipEventDisableTiming));
-    for (int g = 0; g < G; ++g)
-        if (!h->gpass[g]) HIPCHK(hipEventCreateWithFlags(&h->gpass[g], hipEventDisableTiming));
-    return NUSLAM_OK;
-}
-// the group streams start behind everything the handle's stream holds / the handle's stream goes on behind all of them
-int groups_fork(nuslam_batch* h, int G)
-{
-    HIPCHK(hipEventRecord(h->gev0, h->stream));
-    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->gev0, 0));
-    for (int g = 0; g < 4; ++g) h->gpass_set[g] = false;
-    return NUSLAM_OK;
-}
-int groups_join(nuslam_batch* h, int G)
-{
-    for (int g = 1; g < G; ++g) {
-        HIPCHK(hipEventRecord(h->gev[g], h->gstream[g]));
-        HIPCHK(hipStreamWaitEvent(h->stream, h->gev[g], 0));
-    }
-    return NUSLAM_OK;
-}
-
-// One known-id tick of a large batch as G groups of filters on G streams: predict, chain, strips and the pass of each group
-// are enqueued on the group's own stream, so the groups' phases slide against each other on the chip.  Same kernels, same
-// per-filter data as the ungrouped tick: same bits.  (The caller forks / joins the streams around a run of such ticks.)
-int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& base, int m, int total, const int* host_ids,
-                    const int* pf_ids, long long pf_stride)
-{
-    if (h->poisoned) return NUSLAM_E_SYNC;
-    h->last_tick = -1;
-    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
-    int rc = NUSLAM_OK;
-    {   // ---- predict (slam_library.cpp:65-148)
-        const View v = h->view();
-        for (int g = 0; g < G && !rc; ++g) {
-            const Sub sb = group_of(h, g, G);
-            TwistArg twg = tw;
-            if (twg.tw) twg.off += (long long)sb.g0 * twg.stride;
-            dim3 grid((h->ld + 255) / 256, 1, sb.Bg), block(256);
-            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, 0, sub_view(v, sb), twg,
-                                          filt<T>(h->P(), h, sb), h->predict_bookkeeping, (T*)nullptr)));
-        }
-        if (rc) return rc;
-        h->sidx ^= 1; h->state_epoch++;
-        h->cidx ^= 1;
-    }
-    const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);
-    double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
-    for (int i0 = 0; i0 < m; i0 += kTickJ) {
-        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, nullptr, nullptr);
-        const View v = h->view();
-        for (int g = 0; g < G && !rc; ++g) {
-            const Sub sb = group_of(h, g, G);
-            const View w = sub_view(v, sb);
-            TickObs og = o;
-            og.off += (long long)sb.g0 * og.stride;                     // (a broadcast trace has stride 0)
-            TickStep* pl = h->tk_plan + (size_t)sb.g0 * kTickJ;
-            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(sb.Bg), dim3(256), 0, w, og, total,
-                                          (const T*)filt<T>(h->P(), h, sb), pl, TickCarry{}, (int*)nullptr, (int*)nullptr)));
-            if (rc) break;
-            double* Kp = h->tk_K + (size_t)sb.g0 * kTickJ * 2 * h->ld;
-            double* Rp = (h->pass_mode == 0 && !may_init) ? nullptr : h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
-            double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
-            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
-                                          sizeof(double) * (h->pass_mode == 0 && !may_init ? kPlanHeadWords : kPlanExactWords) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
-                                          (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, h->pass_mode != 0 ? 0 : (may_init ? 1 : 2))));
-            if (rc) break;
-            // The passes take turns: group g's pass starts when group g-1's (for group 0: the last group's of the previous
-            // round) has ended.  Left to themselves the groups run in step -- pass beside pass, strips beside strips -- and
-            // each kernel just takes G times as long; with the passes in a ring, one group's HBM-bound pass always runs beside
-            // the other groups' chains and strips.
-            const int prev = (g + G - 1) % G;
-            if (h->gpass_set[prev]) HIPCHK(hipStreamWaitEvent(sb.st, h->gpass[prev], 0));
-            rc = launch_pass(h, v, og.J, h->tk_plan, false, may_init, sb);
-            if (rc) break;
-            HIPCHK(hipEventRecord(h->gpass[g], sb.st));
-            h->gpass_set[g] = true;
-        }
-        if (rc) return rc;
-        h->sidx ^= 1; h->state_epoch++;
-        h->cidx ^= 1;
-        h->pidx ^= 1;
-    }
-    h->host_seen_valid = false;
-    return NUSLAM_OK;
-}
-
 ObsArg inline_obs(double a, double b, int id, int cartesian)
 {
     ObsArg o;
@@ -1065,15 +922,8 @@ int do_tick(nuslam_batch* h, const TwistArg& tw, ObsArg base, int m, bool known,
         return o;
     };
     for (int i = 0; i < m; ++i) {
-        if (pair && host_ids && h->group >= 4 && i + 3 < m) {
-            rc = do_updatej<4>(h, base, i, host_ids, host_mx, host_my);
-            if (rc) return rc;
-            i += 3;
-            continue;
-        }
         if (pair && i + 1 < m) {
-            rc = (h->group == 3 && host_ids) ? do_updatej<2>(h, base, i, host_ids, host_mx, host_my)
-                                             : do_update2(h, obs_at(i), obs_at(i + 1));
+            rc = do_update2(h, obs_at(i), obs_at(i + 1));
             if (rc) return rc;
             ++i;
             continue;
@@ -1618,13 +1468,6 @@ void free_batch(nuslam_batch* h)
     for (auto e : h->ov_events) (void)hipEventDestroy(e);
     if (h->ov_start) (void)hipEventDestroy(h->ov_start);
     if (h->stream2 && h->stream2 != h->stream) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    for (int g = 1; g < 4; ++g) {
-        if (h->gstream[g]) { (void)hipStreamSynchronize(h->gstream[g]); (void)hipStreamDestroy(h->gstream[g]); }
-        if (h->gev[g]) (void)hipEventDestroy(h->gev[g]);
-    }
-    if (h->gev0) (void)hipEventDestroy(h->gev0);
-    for (int g = 0; g < 4; ++g)
-        if (h->gpass[g]) (void)hipEventDestroy(h->gpass[g]);
     if (h->t0) (void)hipEventDestroy(h->t0);
     if (h->t1) (void)hipEventDestroy(h->t1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1673,13 +1516,11 @@ int alloc_batch(int B, int n, int dtype, int device, nuslam_batch** out)
     return NUSLAM_OK;
 }
 
-// every stream the handle may have work on (the chain stream of overlapped runs, the group streams of interleaved ones)
+// every stream the handle may have work on (its own, the chain stream of overlapped runs)
 int sync_all_streams(nuslam_batch* h)
 {
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->stream2 && h->stream2 != h->stream) HIPCHK(hipStreamSynchronize(h->stream2));
-    for (int g = 1; g < 4; ++g)
-        if (h->gstream[g]) HIPCHK(hipStreamSynchronize(h->gstream[g]));
     return NUSLAM_OK;
 }
 // The rank-2m pass reads all 32 factor rows of a filter's K / V strips every round and masks the unused ones by multiplication:
@@ -1839,7 +1680,7 @@ int restore(nuslam_batch* h, int b, const double* state, const double* cov, int 
     HIPCHK(hipSetDevice(h->device));
     (void)lazy_flush(h);                                   // (whatever was recorded is about to be overwritten; its errors with it)
     { int frc = flush_pending(h); if (frc) return frc; }
-    // (kernels of a failed overlapped / grouped run may still be in flight on the other streams: nothing of theirs may land
+    // (kernels of a failed overlapped run may still be in flight on the chain stream: nothing of theirs may land
     // behind what is written here)
     { int src = sync_all_streams(h); if (src) return src; }
     { int zrc = zero_strips(h, b); if (zrc) return zrc; }
@@ -2254,15 +2095,6 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         }
         rc = NUSLAM_OK;
     }
-    // a large batch on a known-id trace: G groups of filters on G streams (do_tick_grouped)
-    const int G = group_count(h);
-    const bool grouped = G > 1 && known_trace && h->tr_m >= 1 && tick_pipeline_pays(h, h->tr_m) && !h->deferred && !h->dense_predict &&
-                         !front_fits(h, false) && t_end > t_begin;
-    if (grouped) {
-        rc = ensure_groups(h, G);
-        if (!rc) rc = ensure_tick_buffers(h);
-        if (!rc) rc = groups_fork(h, G);
-    }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
         tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
@@ -2274,13 +2106,9 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
         const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
         const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m;
-        if (grouped)
-            rc = do_tick_grouped(h, G, tw, o, h->tr_m, total_landmarks, hid, pfid, (long long)h->tr_ticks * h->tr_m);
-        else
-            rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
-                         (long long)h->tr_ticks * h->tr_m);
+        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
+                     (long long)h->tr_ticks * h->tr_m);
     }
-    if (grouped) { int jrc = groups_join(h, G); if (!rc) rc = jrc; }
     h->id_log = saved_log;
     if (!rc && t_end > t_begin) h->last_tick = t_end - 1;
     return rc;
@@ -2391,7 +2219,6 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
     if (!h) return NUSLAM_E_ARG;
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
     h->pairing = enable != 0;
-    if (enable >= 2) h->group = enable;          // 2: two per pass, 4: four per pass
     return NUSLAM_OK;
 }
 
@@ -2422,13 +2249,6 @@ int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable)
     if (enable == 2 && h->stream2 && h->stream2 != h->stream) return NUSLAM_E_ARG;     // (the hook must be set before the first overlapped run)
     h->overlap = enable < 0 ? -1 : (enable != 0);
     if (enable == 2) h->ov_same_stream = true;
-    return NUSLAM_OK;
-}
-
-int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups)
-{
-    if (!h || groups > 4) return NUSLAM_E_ARG;
-    h->groups = groups < 0 ? -1 : (groups < 1 ? 1 : groups);
     return NUSLAM_OK;
 }
 
@@ -2552,7 +2372,7 @@ int nuslam_ekf_clone(const nuslam_ekf_t* src, nuslam_ekf_t** out)
     if (rc) return rc;
     memcpy(d->Q, s->Q, sizeof(d->Q));
     memcpy(d->R, s->R, sizeof(d->R));
-    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->group = s->group; d->tick_mode = s->tick_mode; d->front = s->front; d->fuse_pass = s->fuse_pass;
+    d->host_seen = s->host_seen; d->host_seen_valid = s->host_seen_valid; d->pairing = s->pairing; d->tick_mode = s->tick_mode; d->front = s->front; d->fuse_pass = s->fuse_pass;
     d->touched = s->touched; d->pass_mode = s->pass_mode; d->rank_tile = s->rank_tile; d->apply_units = s->apply_units;
     d->lazy.on = s->lazy.on;
     rc = [&]() -> int {

@@ -73,7 +73,6 @@ SYMBOLS = [
     ("nuslam_batch_set_tick_mode", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_overlap", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_pass_variant", C.c_int, [_vp, C.c_int]),
-    ("nuslam_batch_set_interleave", C.c_int, [_vp, C.c_int]),
     ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_profile_read", C.c_int, [_vp, C.c_int, _dp, C.POINTER(C.c_longlong)]),
@@ -402,7 +401,7 @@ class Batch:
         _chk(lib().nuslam_batch_set_deferred(self._h, 1 if enable else 0), "batch_set_deferred")
 
     def set_pairing(self, enable=True):
-        """False / True, or the number of corrections per pass (2 or 4)."""
+        """False / True: k_update2 for consecutive plain corrections (tick mode 0)."""
         _chk(lib().nuslam_batch_set_pairing(self._h, int(enable)), "batch_set_pairing")
 
     def set_tick_mode(self, mode):
@@ -413,10 +412,6 @@ class Batch:
         """True / False / None (library default); 2: the test hook (second stream = the handle's own)."""
         _chk(lib().nuslam_batch_set_overlap(self._h, -1 if enable is None else (2 if enable == 2 and enable is not True else (1 if enable else 0))),
              "batch_set_overlap")
-
-    def set_interleave(self, groups):
-        """known-id runs of large batches: 1..4 groups of filters on streams of their own (None / -1: library default)"""
-        _chk(lib().nuslam_batch_set_interleave(self._h, -1 if groups is None else int(groups)), "batch_set_interleave")
 
     def set_pass_variant(self, variant):
         _chk(lib().nuslam_batch_set_pass_variant(self._h, int(variant)), "batch_set_pass_variant")

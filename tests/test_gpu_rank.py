@@ -165,34 +165,6 @@ def test_unknown_association_same_verdicts_covariance_within_rounding(hip, mode)
     assert es < 1e-6 and np.abs(a.cov - b.cov).max() / np.abs(b.cov).max() < 1e-9
 
 
-@pytest.mark.parametrize("variant", ["rank", "exact"])
-@pytest.mark.parametrize("dtype", [0, 1])
-def test_interleaved_groups_are_bit_identical(hip, dtype, variant):
-    """nuslam_batch_set_interleave: a batch's known-id run as 2, 3, 4 groups of filters on streams of their own (uneven group
-    sizes, per-filter traces, a cold start so that first sightings take the exact chain) == the ungrouped run, bit for bit,
-    filter by filter; the statistics vector too."""
-    B, n, m, T = 21, 24, 16, 6
-    traces = [synth.make_trace(n, T, m, seed=900 + k, **EXACT_WHEELS) for k in range(B)]
-    tw = np.stack([t.tw[:, :2] for t in traces]); mx = np.stack([t.mx for t in traces])
-    my = np.stack([t.my for t in traces]); ids = np.stack([t.ids for t in traces]).copy()
-    ids[:, 2, 1] = -1
-    res = []
-    for groups in (1, 2, 3, 4):
-        bt = hip.Batch(B, n, Q, R, dtype=dtype)
-        bt.set_tick_mode(3)                       # (3: never the one-launch form, which small handles would otherwise take)
-        bt.set_pass_variant(hip.PASS_RANK if variant == "rank" else hip.PASS_EXACT)
-        bt.set_interleave(groups)
-        bt.load_trace(tw, mx, my, ids)
-        bt.run(0, 2)
-        bt.run(2, T)
-        assert bt.status() == (-1, 0)
-        res.append(([(bt.state(k), bt.cov(k), bt.seen(k)) for k in range(B)], bt.stats()))
-    for r, st in res[1:]:
-        for k in range(B):
-            assert np.array_equal(res[0][0][k][0], r[k][0]) and np.array_equal(res[0][0][k][1], r[k][1]) and res[0][0][k][2] == r[k][2], k
-        assert np.array_equal(res[0][1], st)
-
-
 @pytest.mark.parametrize("n,m,dtype,cold", [(40, 16, 0, False), (12, 5, 0, True), (60, 37, 0, False), (30, 16, 1, False)])
 def test_rank_form_strips_same_bits_in_every_launch_form(hip, n, m, dtype, cold):
     """With the rank-2m pass the strips carry their panels in rank form in rounds without a first sighting (ekf_tick.h).  Which form
