@@ -1185,6 +1185,15 @@ int serve_associate(nuslam_batch* h, double r, double phi, int* id_out)
 int serve_update(nuslam_batch* h, double r, double phi, int id, bool init)
 {
     nuslam_batch::Serve& sv = h->srv;
+    if (sv.trips == 0) {
+        // The round was opened ahead of its first associateLandmark (predict() of a caller whose last tick associated) and has not
+        // scanned a marker yet: its first command cannot carry a correction.  End it (nothing was written) and let the caller record
+        // this update the lazy way -- the tick's predict has already run.
+        sv.pend = false;
+        int rc = serve_end(h);
+        if (rc) return rc;
+        return -1;
+    }
     if (sv.pend) {
         if (sv.trips >= kTickJ) { int rc = serve_end(h); if (rc) return rc; }
         else {

@@ -303,3 +303,27 @@ def test_state_getter_from_the_host_mirror_equals_the_device_copy(hip):
             c.close()
         assert f.status() == 0
         f.close()
+
+
+def test_a_tick_without_association_after_a_tick_with_it(hip):
+    """A caller whose last tick associated gets its next served round opened by predict() already.  If that tick then brings known
+    ids instead (update() without associateLandmark), the round -- which has not scanned anything -- is ended and the updates are
+    recorded the lazy way: nothing may be lost.  Against the per-call kernels (lazy off) with the exact pass: bit for bit."""
+    n, n_world, m, T = 30, 24, 8, 6
+    Qs = np.diag([1e-4, 1e-4, 1e-4])
+    lm = synth.make_landmarks(n_world)
+    tr = synth.make_trace(n_world, T, m, landmarks=lm, noise_sigma=1e-4)
+    bx, by, wid = synth.warmup_observations(lm, noise_sigma=1e-4)
+    a, b = served_pair(hip, n, Qs, True)
+    for f in (a, b):
+        f.tick(np.zeros(3), bx, by, known_ids=wid)
+    for t in range(T):
+        r, phi = polar(hip, tr.mx[t], tr.my[t])
+        for f in (a, b):
+            if t % 2 == 0:
+                drive_with_association(f, tr.tw[t], r, phi, n)
+            else:                                                       # known ids, fewer than four and more than four recorded calls
+                k = 3 if t == 1 else m
+                drive_like_the_node(f, tr.tw[t], r[:k], phi[:k], tr.ids[t][:k], n, n_world)
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov), "tick %d" % t
+    assert a.seen == b.seen and a.status() == b.status() == 0
