@@ -32,8 +32,9 @@ extern "C" {
 /* 3: nuslam_ekf_predict / _init_landmark / _update of a single filter are RECORDED and applied tick by tick (see "Lazy ticks"
  *    below; nuslam_ekf_set_lazy); nuslam_ekf_tick_ex; nuslam_batch_inject_fault; a poisoned handle (NUSLAM_E_SYNC) comes back only
  *    when every filter has been restored; RETIRED: nuslam_batch_set_interleave (groups of filters on streams of their own: measured
- *    neutral) and the four-corrections-per-pass kernel behind nuslam_batch_set_pairing(h, 4) (slower than pairs).  (Also since 2, not listed then: nuslam_sim_params grew by `fov` and `min_range` --
- *    a caller compiled against the version-1 struct must be rebuilt.) */
+ *    neutral) and the four-corrections-per-pass kernel behind nuslam_batch_set_pairing(h, 4) (slower than pairs).  (Also since 2,
+ *    not listed then: nuslam_sim_params grew by `fov` and `min_range` -- a caller compiled against the version-1 struct must be
+ *    rebuilt.) */
 #define NUSLAM_HIP_ABI_VERSION 3
 
 typedef enum {
@@ -90,8 +91,8 @@ int nuslam_ekf_clone(const nuslam_ekf_t* h, nuslam_ekf_t** out);
 /* Lazy ticks (default ON for handles made by nuslam_ekf_create).  The reference's node drives the filter call by call
  * (slam.cpp:269 predict, :296 initializeLandmark, :318 update); one pass over the covariance per update() is 2 len^2 w bytes each.
  * With lazy ticks nuslam_ekf_predict / _init_landmark / _update only RECORD the call; what has been recorded reaches the device as
- * ONE tick -- the kernels of nuslam_ekf_tick_ex (predict, serial chain and strips in one launch, then one rank-2m pass over the
- * covariance), bit-identical to that entry on the same inputs -- when the next nuslam_ekf_predict arrives or when anything looks at
+ * ONE tick -- the kernels of nuslam_ekf_tick_ex (predict, serial chain, strips and the one rank-2m pass over the covariance as ONE
+ * launch, csrc/ekf_fused.h), bit-identical to that entry on the same inputs -- when the next nuslam_ekf_predict arrives or when anything looks at
  * the filter: a getter, nuslam_ekf_associate, _clone, _sync, _status, _snapshot, _restore, _tick, any nuslam_batch_* call on the
  * handle nuslam_ekf_as_batch returned, _destroy (discards).  Consequences a caller can observe:
  *   - argument errors (a landmark id outside 1..n) are still returned by the call itself; failures detected on the device (a
@@ -100,7 +101,9 @@ int nuslam_ekf_clone(const nuslam_ekf_t* h, nuslam_ekf_t** out);
  *   - an initializeLandmark(z, id) directly followed by update(z, id) with the same z and id (slam.cpp:295-318) becomes that
  *     correction's first-sighting flag; any other initializeLandmark is applied on its own, in order;
  *   - nuslam_ekf_get_seen answers from the host's mirror of `seen` while that is exact (predict / initializeLandmark / update
- *     never move it, slam_library.cpp:188-253) without touching the device.
+ *     never move it, slam_library.cpp:188-253) without touching the device; nuslam_ekf_get_state applies what was recorded and reads
+ *     the state from mapped host memory that the tick's launch itself writes (no stream synchronisation, no device-to-host copy:
+ *     the pass over the covariance may still be running when it returns);
  *   - with nuslam_ekf_associate in the loop (slam.cpp:291) the tick runs as a round SERVED to the host: a resident kernel that takes
  *     the caller's calls from a mailbox in mapped pinned host memory -- associate(z) is one ~3 us round trip plus the O(len) work of
  *     the association and of the correction the caller decided on for the previous marker (nuslam_ekf_update / _init_landmark only
