@@ -255,7 +255,9 @@ int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
  *                filter on the device from the round's plan.
  *   1            always the exact chain (bit-identical to one update() per marker), plain kernel
  *   2            always the exact chain, the two-unit kernel for one large fp64 filter that has the chip to itself
- *   10 + k       as 0 with tile shape k = 0..3 (measurement only) */
+ *   10 + k       as 0 with tile shape k = 0..8 (measurement only)
+ *   20           as 0 with a batch's strips by k_tick_panels (a quad of lanes per index, the round's plan in LDS) where the default takes
+ *                k_tick_strips_lane (a lane per index, the plan through the scalar cache): same bits, measurement / test only */
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant);
 
 /* ------------------------------------------------------------------ Monte-Carlo trace generator */

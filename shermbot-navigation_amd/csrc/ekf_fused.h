@@ -47,7 +47,7 @@ __device__ inline void tick_pass_role(const int b, const int idx, View v, const 
 {
     typedef FusedTile<T> TL;
     typedef Pack16<T> vec_t;
-    constexpr int RB = TL::RB, CB = TL::CB, WC = TL::WC, VEC = TL::VEC, RG = TL::RG, KS = kRankKS, NF = kRankNF;
+    constexpr int RB = TL::RB, CB = TL::CB, WC = TL::WC, VEC = TL::VEC, RG = TL::RG, NF = kRankNF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave % WC;

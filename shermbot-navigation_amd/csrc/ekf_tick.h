@@ -1403,6 +1403,169 @@ __global__ __launch_bounds__(IDX * 8) __attribute__((amdgpu_waves_per_eu(1, IDX 
     else body(std::false_type{});
 }
 
+// ------------------------------------------------------------------------------------------------ strips of a batch, rank form
+// Many filters, a round the host has proven free of first sightings (rank_ok == 2 above), nobody reading the R strips: ONE LANE per
+// (state index, role) instead of a quad, and no LDS.  What a correction needs besides the lane's own 35 panel entries -- H_s, S_s^-1,
+// the K / V rows of the index set -- is the same for every lane of a wave (one filter per workgroup): it comes through the SCALAR cache
+// (the plan read through the constant address space) and enters the FMAs as SGPR operands: per index and correction 10 + 2 x |live
+// positions| FMAs -- k_tick_panels<T, 64> spends ten DPP moves, nine 16-byte LDS reads and eighteen selects per LANE of the quad on the
+// same work.  185 us against 287 at 1024 x N = 200 (DESIGN 3c has the breakdown: the kernel moves ~0.8 GB -- the row panel is read one
+// 8-byte entry per 64-byte line of a column-major matrix -- and that, not the arithmetic, is what is left).  Latency is hidden by
+// occupancy (5 waves per SIMD), not by scheduling across corrections, so the corrections may branch.
+// Same sums in the same order as k_tick_panels' rank form: same bits (tests/test_gpu_rank.py).
+#include "ekf_strips_blocks.inc"
+// The K / V rows of the index set enter the panel FMAs as scalar operands, a BLOCK of up to 15 positions per scalar round trip
+// (ekf_strips_blocks.inc, written by tools/gen_strips_asm.py: s_load_dwordx4 per position into a clobbered SGPR window, one wait, two FMAs
+// per position).  Positions 0..2 are always live; of 3..34 those of this and earlier markers ([3, 5 + 2 st)) are dead -- never read
+// again --: runs [3..14], [15..26], [27..34] are dropped once entirely dead, a partly dead run is computed whole (its dead entries take
+// values nobody reads).  ROLE picks the half of a KV row (K: bytes 0..15, V: bytes 16..31) and the operand order of the FMAs.
+#define LANE_PANEL_UPDATE(ROLE, R, st, ps_addr, a, b) do { \
+        const unsigned long long kv__ = (ps_addr) + offsetof(TickStep, KV) + 16 * (ROLE); \
+        if ((st) <= 4) { \
+            LANE_BLOCK_A12_R##ROLE(R, 3, a, b, kv__, kv__ + 32 * 3); \
+            LANE_BLOCK_B12_R##ROLE(R, 15, a, b, kv__, kv__ + 32 * 15); \
+            LANE_BLOCK_B8_R##ROLE(R, 27, a, b, kv__, kv__ + 32 * 27); \
+        } else if ((st) <= 10) { \
+            LANE_BLOCK_A12_R##ROLE(R, 15, a, b, kv__, kv__ + 32 * 15); \
+            LANE_BLOCK_B8_R##ROLE(R, 27, a, b, kv__, kv__ + 32 * 27); \
+        } else if ((st) <= 14) { \
+            LANE_BLOCK_A8_R##ROLE(R, 27, a, b, kv__, kv__ + 32 * 27); \
+        } else { \
+            LANE_BLOCK_A0_R##ROLE(R, 0, a, b, kv__, kv__); \
+        } \
+    } while (0)
+template <typename T>
+__global__ __launch_bounds__(128) void k_tick_strips_lane(View v, TickObs o, const T* __restrict__ P, const TickStep* __restrict__ plan,
+                                                          double* __restrict__ Kbuf, double* __restrict__ Vbuf)
+{
+    constexpr int NU = kTickNU;
+    typedef const __attribute__((address_space(4))) TickStep* ConstPlan;
+    // workgroup -> (filter, group of 64 indices): consecutive workgroups go to the eight XCDs in turn, so XCD x takes filters x, x + 8, ...
+    // and the groups of one filter follow each other on ONE XCD -- its plan is fetched into one L2, once
+    const int ld = v.ld, L = v.L, J = o.J;
+    const int G = (ld + 63) >> 6;
+    const int slot = (int)blockIdx.x >> 3;
+    const int b = ((int)blockIdx.x & 7) + 8 * (slot / G);
+    if (b >= v.B) return;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int t = (slot % G) * 64 + ((int)threadIdx.x & 63);
+    const T* Pb = P + (size_t)b * v.p_stride;
+    ConstPlan pl = (ConstPlan)(unsigned long long)(plan + (size_t)b * kTickJ);
+    const unsigned long long plan_addr = (unsigned long long)(plan + (size_t)b * kTickJ);
+    // the scalar loads below come one correction at a time and would each wait for HBM (the plan is 94 MB at 1024 filters, written by the
+    // chain kernel before): every line this wave is going to read is touched here, all at once, and is in the L2 by the time it is asked for
+    {
+        const int lane = (int)threadIdx.x & 63;
+        const char* base = reinterpret_cast<const char*>(plan + (size_t)b * kTickJ);
+        const size_t kv0 = offsetof(TickStep, KV);
+        // lanes 0..3: the prefix (176 bytes); lanes 4..23: the KV rows (1120 bytes), 64 bytes apart
+        const size_t off = lane < 4 ? (size_t)lane * 64 : kv0 + (size_t)(lane - 4) * 64;
+        const bool on = lane < 4 ? off < (size_t)kPlanPrefixWords * 8 : (lane < 24 && off < sizeof(TickStep));
+        for (int st = 0; st < J; ++st) {
+            if (on) {
+                const double x = *reinterpret_cast<const double*>(base + (size_t)st * sizeof(TickStep) + (off & ~(size_t)7));
+                asm volatile("" :: "v"(x));
+            }
+        }
+    }
+    // the index set of the round (wave-uniform): lane s fetches marker s's id -- ONE load --, the lanes' values go to scalars
+    int U[NU];
+    {
+        const int lane = (int)threadIdx.x & 63;
+        int id = 0;
+        if (o.ids) {
+            if (lane < J) id = o.ids[b * o.stride + o.off + lane];
+        } else {
+#pragma unroll
+            for (int st = 0; st < kTickJ; ++st) id = (lane == st && st < J) ? o.id0[st] : id;
+        }
+        const int cl = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;
+#pragma unroll
+        for (int p = 0; p < NU; ++p) U[p] = p < 3 ? p : __builtin_amdgcn_readlane(cl, (p - 3) >> 1) + ((p - 3) & 1);
+    }
+    if (role == 0) {
+        // ---- column t of the row panel; V_s(:, t)
+        const bool live = t < L;
+        const T* col = Pb + (size_t)(live ? t : 0) * ld;
+        double* const Vb = Vbuf + (size_t)b * kTickJ * 2 * ld + t;
+        double RP[NU];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) RP[p] = (double)col[U[p]];
+        // (the panel has ARRIVED before the corrections begin, and the compiler knows it: left to its own bookkeeping across the branches
+        // below it waits for vmcnt(0) -- the correction's own stores -- at the top of every correction)
+#pragma unroll
+        for (int p = 0; p < NU; ++p) asm volatile("" :: "v"(RP[p]));
+#pragma unroll
+        for (int st = 0; st < kTickJ; ++st) {
+            ConstPlan ps = pl + (st < J ? st : 0);
+            if (st < J && ps->skip == 0) {
+            const int pos = 3 + 2 * st;
+            const double rs[5] = { RP[0], RP[1], RP[2], RP[pos], RP[pos + 1] };
+            double Hc[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+            const double V0 = hp_entry(Hc, rs, 0), V1 = hp_entry(Hc, rs, 1);
+            if (live) {
+                __builtin_nontemporal_store(V0, &Vb[(size_t)(st * 2 + 0) * ld]);
+                __builtin_nontemporal_store(V1, &Vb[(size_t)(st * 2 + 1) * ld]);
+            }
+            // RP[p] = fma(V1, -K_s(U[p], 1), fma(V0, -K_s(U[p], 0), RP[p])) for the live p
+            LANE_PANEL_UPDATE(0, RP, st, plan_addr + (unsigned long long)st * sizeof(TickStep), V0, V1);
+            }
+        }
+    } else {
+        // ---- row t of the column panel; K_s(t, :); state entry t
+        const bool live = t < ld;
+        const int tr = live ? t : 0;
+        double* const Kb = Kbuf + (size_t)b * kTickJ * 2 * ld + tr;
+        double CP[NU];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) CP[p] = (double)Pb[(size_t)U[p] * ld + tr];
+        double sv = v.s_in[(size_t)b * ld + tr];
+#pragma unroll
+        for (int p = 0; p < NU; ++p) asm volatile("" :: "v"(CP[p]));
+        asm volatile("" :: "v"(sv));
+#pragma unroll
+        for (int st = 0; st < kTickJ; ++st) {
+            ConstPlan ps = pl + (st < J ? st : 0);
+            const int c = ps->c;
+            const bool act = st < J && ps->skip == 0, init = (ps->init & 1) != 0;
+            // (the state's scalars come with the entry's head, unconditionally, and enter through selects: a branch around them made every
+            // correction wait for its own stores)
+            const double lx = ps->lxy[0], ly = ps->lxy[1], head = ps->heading, dz0 = ps->dz[0], dz1 = ps->dz[1];
+            const bool at0 = init && t == c, at1 = init && t == c + 1;
+            if (st < J && !act) {                                       // the landmark was initialised before update() threw
+                sv = at0 ? lx : sv;
+                sv = at1 ? ly : sv;
+            }
+            if (act) {                                                  // (uniform)
+            const int pos = 3 + 2 * st;
+            const int setv[5] = { 0, 1, 2, c, c + 1 };
+            const double pc[5] = { CP[0], CP[1], CP[2], CP[pos], CP[pos + 1] };
+            double Hc[10], Si[4], K[2], m[5];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) Hc[q] = ps->Hc[q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Si[q] = ps->Sinv[q];
+            gain_row(pc, Hc, Si, t, setv, K, m);
+            if (live) {
+                __builtin_nontemporal_store(K[0], &Kb[(size_t)(st * 2 + 0) * ld]);
+                __builtin_nontemporal_store(K[1], &Kb[(size_t)(st * 2 + 1) * ld]);
+            }
+            double s0 = at0 ? lx : at1 ? ly : sv;
+            double acc = 0.0;
+            acc = fma(K[0], dz0, acc);
+            acc = fma(K[1], dz1, acc);
+            s0 = s0 + acc;                                              // :275
+            sv = t == 0 ? head : s0;                                    // :276 (wrapped by the chain)
+            // CP[p] = fma(V_s(1, U[p]), -K[1], fma(V_s(0, U[p]), -K[0], CP[p])) for the live p
+            LANE_PANEL_UPDATE(1, CP, st, plan_addr + (unsigned long long)st * sizeof(TickStep), K[0], K[1]);
+            }
+        }
+        if (live) v.s_out[(size_t)b * ld + t] = sv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ chain and strips in one launch
 // One filter (or few): the strips need nothing of correction s but plan entry s, and a correction of the chain takes ~2.2 us
 // where the strips' share of it takes ~0.6.  k_tick_front runs the chain on workgroup 0 and the strip workgroups BESIDE it

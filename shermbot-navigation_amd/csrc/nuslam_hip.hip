@@ -112,6 +112,7 @@ struct nuslam_batch {
     // for rounds with a first sighting; 1 = always the exact chain, plain kernel; 2 = always the exact chain, two-unit
     // kernel where it applies; 10 + k = as 0 with tile shape k (experiments)
     int pass_mode = 0, rank_tile = 0;
+    int strips_lane = 1;       // batches, rank form proven by the host: k_tick_strips_lane; 0 (variant 20): k_tick_panels<T, 64> as before
     std::vector<unsigned char> touched;   // [B][n + 1]: landmarks the host can PROVE have been corrected at least once (known-id
                                // ticks, restore): a round of such ids cannot cancel an INT_MAX diagonal, so the exact-chain
                                // pass need not be launched behind the rank-2m one
@@ -687,7 +688,11 @@ int launch_strips_and_pass(nuslam_batch* h, const View& v, const TickObs& o, con
     // for the entries' heads only)
     const int rank_ok = h->pass_mode != 0 ? 0 : (may_init ? 1 : 2);
     const size_t plan_lds = sizeof(double) * (rank_ok == 2 ? kPlanHeadWords : kPlanExactWords) * (size_t)o.J;
-    if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)        // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
+    if (rank_ok == 2 && !rbuf && vbuf && !compact && h->strips_lane && (long long)((h->ld + 63) / 64) * h->B > 4 * h->n_cu)
+        // many filters, rank form proven, no R strips wanted: a lane per (index, role), coefficients through the scalar cache
+        DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_PANELS, k_tick_strips_lane<T>, dim3(8 * ((h->B + 7) / 8) * ((h->ld + 63) / 64)), dim3(128),
+                                   v, o, (const T*)h->P(), plan, h->tk_K, vbuf)));
+    else if ((long long)((h->ld + 31) / 32) * h->B <= h->n_cu)   // few filters: 4-wave groups, one wave per SIMD, on twice the CUs
         DISPATCH_T(h, rc = (launch_lds(h, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 32>, dim3((h->ld + 31) / 32, h->B), dim3(256),
                                        plan_lds, v, o, (const T*)h->P(), plan, h->tk_K, rbuf, vbuf, (const int*)(compact ? h->tk_posmap : nullptr),
                                        h->tk_KU, h->tk_RU, h->tk_SU, rank_ok)));
@@ -2243,8 +2248,10 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 
 int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
 {
-    if (!h || variant < 0 || (variant > 2 && variant < 10) || variant > 18) return NUSLAM_E_ARG;
+    if (!h || variant < 0 || (variant > 2 && variant < 10) || (variant > 18 && variant != 20)) return NUSLAM_E_ARG;
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
+    h->strips_lane = variant != 20;
+    if (variant == 20) variant = 0;
     if (variant >= 10) { h->pass_mode = 0; h->rank_tile = variant - 10; return NUSLAM_OK; }
     h->pass_mode = variant;
     h->rank_tile = 0;

@@ -143,6 +143,39 @@ def test_batch_with_per_filter_ids_and_tile_shapes(hip):
         assert np.array_equal(g.state, ref[k][0]) and np.array_equal(g.cov, ref[k][1])
 
 
+@pytest.mark.parametrize("n,B,dtype", [(30, 1100, 0), (200, 150, 0), (30, 1100, 1)])
+def test_batch_strips_a_lane_per_index_same_bits_as_the_quads(hip, n, B, dtype):
+    """Enough filters to fill the chip four times over, a round the host proves free of first sightings: the strips are formed by
+    k_tick_strips_lane (a lane per index and role, the plan through the scalar cache) -- against k_tick_panels<T, 64> (variant 20:
+    quads, the plan in LDS) on the same trace: per-filter ids, a skipped marker, the same landmark twice, a bad id, fewer markers
+    than a round.  Identical state and covariance in every filter."""
+    m, T, K = 16, 5, 8
+    lm = synth.make_landmarks(n)
+    traces = [synth.make_trace(n, T, m, seed=500 + k, landmarks=lm, **EXACT_WHEELS) for k in range(K)]
+    pick = np.arange(B) % K
+    tw = np.stack([t.tw[:, :2] for t in traces])[pick]; mx = np.stack([t.mx for t in traces])[pick]
+    my = np.stack([t.my for t in traces])[pick]; ids = np.stack([t.ids for t in traces])[pick].copy()
+    ids[1::3, 1, 4] = -1                              # a marker update() is not called for
+    ids[2::5, 2, 7] = ids[2::5, 2, 3]                 # the same landmark twice in a round
+    ids[4::7, 3, 0] = n + 5                           # an id outside the map: NUSLAM_E_BOUNDS latched, nothing applied
+    bx, by, wid = synth.warmup_observations(lm)
+    out = []
+    for variant in (hip.PASS_RANK, 20):
+        bt = hip.Batch(B, n, Q, R, dtype=dtype)
+        bt.set_pass_variant(variant)
+        bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+        bt.run(0, 1)
+        bt.load_trace(tw, mx, my, ids)
+        bt.run(0, T)
+        bt.load_trace(tw[:, :2], mx[:, :2, :5], my[:, :2, :5], ids[:, :2, :5])      # five markers per tick
+        bt.run(0, 2)
+        out.append((bt.status(), [(bt.state(k), bt.cov(k)) for k in range(0, B, max(1, B // 64))]))
+    assert out[0][0] == out[1][0]
+    for (s0, p0), (s1, p1) in zip(out[0][1], out[1][1]):
+        assert np.isfinite(p0).all()
+        assert np.array_equal(s0, s1) and np.array_equal(p0, p1)
+
+
 @pytest.mark.parametrize("mode", [1, 2], ids=["resident-round", "launch-per-marker"])
 def test_unknown_association_same_verdicts_covariance_within_rounding(hip, mode):
     """associateLandmark in front of every correction (slam_library.cpp:188-253): the verdicts are threshold decisions on
