@@ -279,11 +279,13 @@ __device__ inline void predict_block(const View& v, const MotionStep& ms, const 
 }
 
 #ifdef NUSLAM_CHAIN_CLOCK
-__device__ long long g_front_tl[16];          // debug builds: absolute 100 MHz stamps of one k_tick_front launch (TL below)
+__device__ long long g_front_tl[32];          // debug builds: absolute 100 MHz stamps of one k_tick_front launch (TL below)
 #define TL(k, cond) do { if (cond) g_front_tl[k] = (long long)wall_clock64(); } while (0)
+#define TLMAX(k, cond) do { if (cond) atomicMax(reinterpret_cast<unsigned long long*>(&g_front_tl[k]), (unsigned long long)wall_clock64()); } while (0)
 __device__ long long g_chain_clock[32];       // debug builds: per wave, 100 MHz ticks spent in each phase of the loop
 #else
 #define TL(k, cond) do { } while (0)
+#define TLMAX(k, cond) do { } while (0)
 #endif
 // ------------------------------------------------------------------------------------------------ the next tick's start
 // P after the previous tick's corrections and this tick's predict, restricted to this tick's index set U' -- WITHOUT
@@ -487,6 +489,23 @@ struct TickTagged {
     long long* mtags;
     long long mseq;
 };
+// k_run_fused (ekf_fused.h): the ticks of a resident trace inside ONE launch, the covariance resident in the pass workgroups' registers
+// in between.  A role is then called once per tick (RUN): what another workgroup left in the PREVIOUS tick of the same launch -- the
+// state, the rows / columns of P the pass workgroups exported -- is read with agent-scope loads, behind a count of the workgroups that
+// have finished that tick (strips: state stored; pass: exports stored).
+struct TickRun {
+    int* done;             // one word per strip workgroup, then one per pass workgroup: the last tick (a running number) the workgroup has
+                           // finished -- state stored / exports stored.  (A shared counter serialises ~400 device-scope atomics per tick.)
+    int* done_all;         // one word per pass workgroup: ALL of its exports of that tick are stored (`done`'s pass words say so of the entries
+                           // the chain gathers -- row AND column in the next index set --, which a workgroup stores first: the rest, the
+                           // rows / columns the strips read, is waited for by the predict role, off the chain's path)
+    int stamp;             // this tick's number: what a workgroup leaves in its word; the chain waits for every word to reach stamp - 1
+    int first;             // != 0: the launch's first tick -- nothing to wait for
+    int stamp_dbg_second_last;   // (debug timeline: the launch's second-to-last tick)
+    long long toff;        // this tick's offset into the resident trace, added to TickObs::off
+    int* timeouts;         // expired waits (NUSLAM_E_SYNC)
+    int n_strip, n_pass, tiles_r, tiles_c;   // the words that exist; pass workgroup idx is live iff ((idx >> 3) / tiles_c) * 8 + (idx & 7) < tiles_r
+};
 __device__ inline void st_sys(double* p, double x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline void st_sys(long long* p, long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // { half, tag } words of a tagged strip element
@@ -517,11 +536,12 @@ __device__ inline void plan_store_head(bool publish, TickStep* ps, int skip, int
     } else { ps->skip = skip; ps->init = init; ps->c = c; ps->id = id; }
 }
 
-template <typename T, bool FUSED, bool PUBLISH>
+template <typename T, bool FUSED, bool PUBLISH, bool RUN = false>
 __device__ inline void tick_chain(const int b, View v, TickObs o, int total_landmarks, const T* __restrict__ P,
                                   TickStep* __restrict__ plan, TickCarry cy,
-                                  int* __restrict__ ctrl_out4, int* __restrict__ done_cnt, TickPublish pub)
+                                  int* __restrict__ ctrl_out4, int* __restrict__ done_cnt, TickPublish pub, TickRun rn = TickRun{})
 {
+    const long long ooff = RUN ? o.off + rn.toff : o.off;
     constexpr int NU = kTickNU;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -549,7 +569,7 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
 
     if (tid < kTickJ) {
         int id = 0;
-        if (tid < J) id = o.ids ? o.ids[b * o.stride + o.off + tid] : o.id0[tid];
+        if (tid < J) id = o.ids ? o.ids[b * o.stride + ooff + tid] : o.id0[tid];
         idsh[tid] = id;
         const int c = (id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3;      // always a readable index
         Ush[3 + 2 * tid] = c;
@@ -566,17 +586,48 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
         // 35 x 35 block -- and what does not need the block is computed while it is on its way: the motion step's sines and
         // cosines (motion_step), the markers' polar forms.
         const bool fpred = PUBLISH && pub.predict;                      // the tick's predict runs in THIS launch (k_tick_front)
+        if constexpr (RUN) {
+            // the previous tick of this launch is complete: every strip workgroup has stored its state entries, every pass workgroup the
+            // rows / columns of this tick's index set (bounded: an expired wait goes on and is reported, as everywhere)
+            if (!rn.first) {                                            // (uniform) every thread looks at its share of the words
+                // (a thread's words are asked for TOGETHER: an agent-scope load is a ~1.5 us round trip)
+                constexpr int kWordsPerThread = 4;                      // (up to 1024 words)
+                const int nw = rn.n_strip + rn.n_pass;
+                int wi[kWordsPerThread];
+                bool need[kWordsPerThread];
+#pragma unroll
+                for (int q = 0; q < kWordsPerThread; ++q) {
+                    const int w = tid + 256 * q, idx = w - rn.n_strip;
+                    need[q] = w < nw && !(idx >= 0 && ((idx >> 3) / rn.tiles_c) * 8 + (idx & 7) >= rn.tiles_r);      // (no such tile)
+                    wi[q] = need[q] ? w : 0;
+                }
+                bool ok = false;
+                for (int it = 0; it < (1 << 20) && !ok; ++it) {
+                    int val[kWordsPerThread];
+#pragma unroll
+                    for (int q = 0; q < kWordsPerThread; ++q) val[q] = need[q] ? ld_agent(rn.done + wi[q]) : 0;
+                    ok = true;
+#pragma unroll
+                    for (int q = 0; q < kWordsPerThread; ++q) {
+                        if (need[q] && seq_reached(val[q], rn.stamp - 1)) need[q] = false;
+                        ok = ok && !need[q];
+                    }
+                }
+                if (!__syncthreads_and(ok ? 1 : 0) && tid == 0) atomicAdd(rn.timeouts, 1);
+            }
+            TL(16, b == 0 && tid == 0);                                 // run: the previous tick's state and block entries are stored
+        }
         double dth = 0.0, dxx = 0.0, theta = 0.0;
         if (fpred) {
             const TwistArg& tw = pub.tw;
             dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
             dxx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
-            theta = s[0];
+            theta = RUN ? ld_agent(&s[0]) : s[0];
         }
         double oa = 0.0, ob = 0.0;
         if (wave == 3 && lane < J) {
-            oa = o.a ? o.a[b * o.stride + o.off + lane] : o.a0[lane];
-            ob = o.b ? o.b[b * o.stride + o.off + lane] : o.b0[lane];
+            oa = o.a ? o.a[b * o.stride + ooff + lane] : o.a0[lane];
+            ob = o.b ? o.b[b * o.stride + ooff + lane] : o.b0[lane];
         }
         const int* ci = v.c_in + b * C_WORDS;
         seen = ci[C_SEEN]; brk = ci[C_BRK]; status = ci[C_STATUS]; cached = ci[C_SEEN_CACHED];
@@ -588,18 +639,21 @@ __device__ inline void tick_chain(const int b, View v, TickObs o, int total_land
             // read costs ~16 cycles of this CU's one address path: 1225 of them were 8 us of every tick)
             const int e = tid + 256 * u, ec = e < NU * NU ? e : 0;
             const int q = ec / NU, p = ec % NU;
-            g[u] = (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
+            g[u] = RUN ? (double)ld_agent(&Pb[(size_t)Ush[q] * ld + Ush[p]]) : (double)Pb[(size_t)Ush[q] * ld + Ush[p]];
             // fpred: the entry of row 0 (column 0) predict combines it with (predict_block's column / row role), fetched by the
             // thread itself so that predict can be applied before anything passes through LDS
             gp[u] = 0.0;
             {
                 const bool colr = q >= 3 && (p == 1 || p == 2), rowr = p >= 3 && (q == 1 || q == 2);
-                if (fpred && (colr || rowr)) gp[u] = (double)Pb[(size_t)(rowr ? 0 : Ush[q]) * ld + (colr ? 0 : Ush[p])];   // (128 of the 1225)
+                if (fpred && (colr || rowr)) {                          // (128 of the 1225)
+                    const T* gsrc = &Pb[(size_t)(rowr ? 0 : Ush[q]) * ld + (colr ? 0 : Ush[p])];
+                    gp[u] = RUN ? (double)ld_agent(gsrc) : (double)*gsrc;
+                }
             }
         }
         double gc = 0.0;                                                // the 3 x 3 pose corner, entry (i, j) on lane i + 3 j of wave 0
-        if (fpred && tid < 9) gc = (double)Pb[(size_t)(tid / 3) * ld + tid % 3];
-        const double gs = s[Ush[tid < NU ? tid : 0]];
+        if (fpred && tid < 9) gc = RUN ? (double)ld_agent(&Pb[(size_t)(tid / 3) * ld + tid % 3]) : (double)Pb[(size_t)(tid / 3) * ld + tid % 3];
+        const double gs = RUN ? ld_agent(&s[Ush[tid < NU ? tid : 0]]) : s[Ush[tid < NU ? tid : 0]];
         MotionStep ms{};
         if (fpred) ms = motion_step(theta, dth, dxx);
         if (wave == 3 && lane < kTickJ) {         // all markers' polar forms at once, one lane each
@@ -1578,14 +1632,15 @@ __global__ __launch_bounds__(128) void k_tick_strips_lane(View v, TickObs o, con
 constexpr int kPlanWords = (int)(sizeof(TickStep) / 8);
 
 // TAGGED (k_tick_fused only): rank-form strips whose K / V go out as tagged words (tg) instead of into Kbuf / Vbuf
-template <typename T, bool TAGGED = false>
+template <typename T, bool TAGGED = false, bool RUN = false>
 __device__ inline void tick_panels_stream(const int b, const int wg, View v, TickObs o, const T* __restrict__ P,
                                           const TickStep* __restrict__ plan, double* __restrict__ Kbuf,
                                           double* __restrict__ Rbuf, double* __restrict__ Vbuf, TickPublish pub,
                                           int* __restrict__ timeouts, const int* __restrict__ posmap = nullptr,
                                           double* __restrict__ KU = nullptr, double* __restrict__ RU = nullptr,
-                                          double* __restrict__ SU = nullptr, TickTagged tg = TickTagged{})
+                                          double* __restrict__ SU = nullptr, TickTagged tg = TickTagged{}, TickRun rn = TickRun{})
 {
+    const long long ooff = RUN ? o.off + rn.toff : o.off;
     // posmap != null (streamed overlapped runs, k_tick_strips): the strips at the NEXT tick's index set are also dropped into the
     // compact arrays KU, RU, SU for that tick's chain (tick_carry), as k_tick_panels does
     constexpr int NU = kTickNU, IDX = 32;
@@ -1611,7 +1666,7 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         else if (p < NU) {
             const int st = (p - 3) >> 1;
             int id = 0;
-            if (st < J) id = o.ids ? o.ids[b * o.stride + o.off + st] : o.id0[st];
+            if (st < J) id = o.ids ? o.ids[b * o.stride + ooff + st] : o.id0[st];
             u = ((id >= 1 && id <= v.n) ? 3 + 2 * (id - 1) : 3) + ((p - 3) & 1);
         }
         Uk[j] = u;
@@ -1837,7 +1892,14 @@ __device__ inline void tick_panels_stream(const int b, const int wg, View v, Tic
         if (rankp) loop(std::true_type{});
         else loop(std::false_type{});
     }
-    if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
+    if constexpr (RUN) {
+        // the next tick's chain (another workgroup, this launch) reads the state: agent-scope store, then this workgroup counts itself done
+        if (role == 1 && owner) st_agent(&v.s_out[(size_t)b * ld + t], sv);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) st_agent(rn.done + wg, rn.stamp);
+        TLMAX(23, threadIdx.x == 0 && !rn.first && rn.stamp_dbg_second_last);
+    } else if (role == 1 && owner) v.s_out[(size_t)b * ld + t] = sv;
     if constexpr (TAGGED) {
         if (tg.mirror) {                                                // (uniform)
             if (role == 1 && owner) st_sys(tg.mirror + t, sv);
@@ -1882,10 +1944,13 @@ __global__ __launch_bounds__(256) void k_tick_chain_pub(View v, TickObs o, int t
 // The tick's predict as workgroups of k_tick_front (thread t: column t of rows 1, 2, row t of columns 1, 2, state entry t; thread
 // 0 the 3 x 3 corner + Q -- k_predict's arithmetic, slam_library.cpp:65-148).  They start when the chain has gathered its block
 // from the covariance BEFORE predict, store with agent-scope stores, and count themselves done for the strip workgroups.
-template <typename T>
+template <typename T, bool RUN = false>
 __device__ inline void tick_predict_role(const int b, const int blk, View v, TickPublish pub, T* __restrict__ P,
-                                         int* __restrict__ timeouts)
+                                         int* __restrict__ timeouts, TickRun rn = TickRun{})
 {
+    // RUN (k_run_fused): state and covariance were left by other workgroups in the previous tick of this launch: agent-scope loads
+    auto ldp = [](const T* q) -> double { if constexpr (RUN) return (double)ld_agent(q); else return (double)*q; };
+    auto lds = [](const double* q) -> double { if constexpr (RUN) return ld_agent(q); else return *q; };
     if (threadIdx.x == 0) {
         int ok = 0;
         for (int it = 0; it < (1 << 18); ++it) {
@@ -1895,6 +1960,34 @@ __device__ inline void tick_predict_role(const int b, const int blk, View v, Tic
         if (!ok) atomicAdd(timeouts, 1);               // (goes on all the same: every wait of this launch is bounded)
     }
     __syncthreads();
+    if constexpr (RUN) {
+        // the previous tick's pass workgroups have stored everything they export (the edge tiles this role rewrites, the rows / columns
+        // the strips will read once this role has counted itself done)
+        if (!rn.first) {
+            constexpr int kWordsPerThread = 4;
+            int wi[kWordsPerThread];
+            bool need[kWordsPerThread];
+#pragma unroll
+            for (int q = 0; q < kWordsPerThread; ++q) {
+                const int idx = (int)threadIdx.x + 256 * q;
+                need[q] = idx < rn.n_pass && ((idx >> 3) / rn.tiles_c) * 8 + (idx & 7) < rn.tiles_r;
+                wi[q] = need[q] ? idx : 0;
+            }
+            bool ok = false;
+            for (int it = 0; it < (1 << 20) && !ok; ++it) {
+                int val[kWordsPerThread];
+#pragma unroll
+                for (int q = 0; q < kWordsPerThread; ++q) val[q] = need[q] ? ld_agent(rn.done_all + wi[q]) : 0;
+                ok = true;
+#pragma unroll
+                for (int q = 0; q < kWordsPerThread; ++q) {
+                    if (need[q] && seq_reached(val[q], rn.stamp - 1)) need[q] = false;
+                    ok = ok && !need[q];
+                }
+            }
+            if (!__syncthreads_and(ok ? 1 : 0) && threadIdx.x == 0) atomicAdd(timeouts, 1);
+        }
+    }
     const int t = blk * 256 + threadIdx.x;
     const int ld = v.ld;
     const double* s = v.s_in + (size_t)b * ld;
@@ -1902,15 +1995,15 @@ __device__ inline void tick_predict_role(const int b, const int blk, View v, Tic
     const TwistArg& tw = pub.tw;
     const double dth = tw.tw ? tw.tw[b * tw.stride + tw.off + 0] : tw.dth0;
     const double dx = tw.tw ? tw.tw[b * tw.stride + tw.off + 1] : tw.dx0;
-    const double theta = s[0];
+    const double theta = lds(&s[0]);
     const MotionStep ms = motion_step(theta, dth, dx);                 // predictEstimate :71-94, getA :127-148
     const double dq_x = ms.dq_x, dq_y = ms.dq_y, th1 = ms.th1, a1 = ms.a1, a2 = ms.a2;
-    if (t < ld) st_agent(&so[t], t == 0 ? th1 : t == 1 ? s[1] + dq_x : t == 2 ? s[2] + dq_y : s[t]);
+    if (t < ld) st_agent(&so[t], t == 0 ? th1 : t == 1 ? lds(&s[1]) + dq_x : t == 2 ? lds(&s[2]) + dq_y : lds(&s[t]));
     T* Pb = P + (size_t)b * v.p_stride;
     if (t == 0) {
         double p[3][3], tt[3][3], u[3][3];
         for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) p[i][j] = (double)Pb[(size_t)j * ld + i];
+            for (int i = 0; i < 3; ++i) p[i][j] = ldp(&Pb[(size_t)j * ld + i]);
         for (int j = 0; j < 3; ++j) {
             tt[0][j] = p[0][j];
             tt[1][j] = a1 * p[0][j] + p[1][j];
@@ -1925,11 +2018,11 @@ __device__ inline void tick_predict_role(const int b, const int blk, View v, Tic
             for (int i = 0; i < 3; ++i) st_agent(&Pb[(size_t)j * ld + i], (T)(u[i][j] + v.Q[i + 3 * j]));
     } else if (t >= 3 && t < v.L) {
         T* col = Pb + (size_t)t * ld;
-        const double p0 = (double)col[0];
-        const double p1 = (double)col[1];
-        const double p2 = (double)col[2];
-        const double t0 = (double)Pb[t];
-        const double r1 = (double)Pb[(size_t)1 * ld + t], r2 = (double)Pb[(size_t)2 * ld + t];
+        const double p0 = ldp(&col[0]);
+        const double p1 = ldp(&col[1]);
+        const double p2 = ldp(&col[2]);
+        const double t0 = ldp(&Pb[t]);
+        const double r1 = ldp(&Pb[(size_t)1 * ld + t]), r2 = ldp(&Pb[(size_t)2 * ld + t]);
         st_agent(&col[1], (T)(a1 * p0 + p1));
         st_agent(&col[2], (T)(a2 * p0 + p2));
         st_agent(&Pb[(size_t)1 * ld + t], (T)(t0 * a1 + r1));

@@ -96,6 +96,9 @@ struct nuslam_batch {
     int* tk_pub = nullptr;     // [B]: the chain's announcements to the strip workgroups of the same launch (k_tick_front)
     unsigned seq_pub = 0, seq_gather = 0, seq_pred = 0;   // (sequence words: they wrap, the device compares wrapped differences)
     int front = 1;             // 1: one filter's chain and strips as ONE launch (k_tick_front) while its grid fits the chip
+    int run_fused = 1;         // nuslam_batch_run on one filter, known ids, no first sighting possible: the run's ticks as ONE launch (k_run_fused)
+    unsigned run_done = 0;     // k_run_fused: the running number of the last tick enqueued (tk_run: the workgroups' words)
+    int* tk_run = nullptr;
     int fuse_pass = 1;         // 1: ... and the rank-2m pass over P as workgroups of that launch too (k_tick_fused, ekf_fused.h) in rounds
                                // the host can prove free of first sightings; 0: the pass as a launch of its own behind it (tick mode 4)
     // the state vector mirrored into mapped pinned host memory by the kernels that produce it (fused ticks, served rounds): get_state
@@ -864,6 +867,81 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
     return NUSLAM_OK;
 }
 
+// nuslam_batch_run, ticks [t0, t1) of ONE filter's resident known-id trace, as ONE launch (k_run_fused, ekf_fused.h): the covariance
+// stays in the pass workgroups' registers between the ticks.  kRunNotApplicable: this handle / this run takes a launch per tick
+// (anything but the default known-id pipeline, a tick that may hold a first sighting, ids the host does not have).
+constexpr int kRunNotApplicable = -2000;
+int run_fused(nuslam_batch* h, int t0, int t1, int total)
+{
+    const int nt = t1 - t0, m = h->tr_m;
+    if (!(h->run_fused && h->fuse_pass && h->front && h->B == 1 && h->pass_mode == 0 && h->rank_tile == 0 && nt >= 2 && m >= 1 && m <= kTickJ &&
+          h->tr_ids && !h->tr_presence_only && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->predict_bookkeeping &&
+          front_fits(h, true) && !h->id_log))
+        return kRunNotApplicable;
+    const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data();
+    const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data();
+    if (!hid && !pfid) return kRunNotApplicable;
+    {   // no tick of the run may hold a first sighting: proven on a COPY of the host's record (a launch per tick proves it again, tick by tick)
+        const std::vector<unsigned char> keep = h->touched;
+        bool may = false;
+        for (int t = t0; t < t1 && !may; ++t)
+            may = tick_may_init_all(h, hid ? hid + (size_t)t * m : nullptr, pfid ? pfid + (size_t)t * m : nullptr, (long long)h->tr_ticks * m, m, total);
+        if (may) { h->touched = keep; return kRunNotApplicable; }
+    }
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    if (h->poisoned) return NUSLAM_E_SYNC;
+    h->last_tick = -1;
+    ObsArg base;
+    base.a = h->tr_mx; base.b = h->tr_my; base.ids = h->tr_ids;
+    base.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * m;
+    base.off = (long long)t0 * m;
+    base.a0 = base.b0 = 0.0; base.id0 = 0; base.cartesian = 1; base.log_slot = -1;
+    const TickObs o = make_tick_obs(h, base, 0, m, nullptr, nullptr, nullptr);
+    View v = h->view();
+    const int strip_wgs = (h->ld + 31) / 32, n_pred = (h->ld + 255) / 256;
+    TickPublish pub;
+    pub.flag = h->tk_pub; pub.base = (int)h->seq_pub; pub.predict = 1;
+    pub.gbase = (int)(h->seq_gather + 1u); pub.pbase = (int)(h->seq_pred + (unsigned)n_pred);
+    pub.rank_panels = 1;
+    pub.tw.tw = h->tr_tw; pub.tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; pub.tw.off = (long long)t0 * 2;
+    pub.tw.dth0 = pub.tw.dx0 = 0.0;
+    if (h->seq_tag > 0x3fffffffu) {                      // (tags advance by one per tick: start over long before they wrap)
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemsetAsync(h->tk_tagK, 0, sizeof(long long) * 2 * kTickJ * 2 * (size_t)h->ld * h->B, h->stream));
+        HIPCHK(hipMemsetAsync(h->tk_tagV, 0, sizeof(long long) * 2 * kTickJ * 2 * (size_t)h->ld * h->B, h->stream));
+        h->seq_tag = 0u;
+    }
+    TickTagged tg;
+    tg.tagK = h->tk_tagK; tg.tagV = h->tk_tagV; tg.tag = (int)(h->seq_tag + 1u);
+    tg.mirror = nullptr; tg.mtags = nullptr; tg.mseq = 0;
+    int n_pass = 0, live = 0;
+    DISPATCH_T(h, n_pass = FusedTile<T>::blocks(h->ld, h->L));
+    DISPATCH_T(h, live = FusedTile<T>::tiles_r(h->ld) * FusedTile<T>::tiles_c(h->L));
+    RunArg ra;
+    if (!h->tk_run) {
+        // [0, 1024) the strips' / pass workgroups' words, [1024, 2048) the pass workgroups' second words
+        const size_t bytes = sizeof(int) * 2048;
+        HIPCHK(hipMalloc(&h->tk_run, bytes));
+        HIPCHK(hipMemsetAsync(h->tk_run, 0, bytes, h->stream));
+    }
+    if (strip_wgs + n_pass > 1024) return kRunNotApplicable;
+    (void)live;
+    ra.ticks = nt; ra.m = m; ra.done = h->tk_run; ra.done_all = h->tk_run + 1024; ra.done_base = (int)h->run_done; ra.n_strip = strip_wgs; ra.n_pass = n_pass;
+    ra.ids = o.ids; ra.ids_stride = o.stride; ra.ids_off = o.off;
+    int rc = NUSLAM_OK;
+    DISPATCH_T(h, rc = (launch(h, NUSLAM_K_TICK_CHAIN, k_run_fused<T>, dim3(1 + n_pred + strip_wgs + n_pass, 1), dim3(256), v, o, total,
+                               (T*)h->P(), (T*)h->Palt(), h->tk_plan, h->tk_K, h->tk_R, h->tk_V, pub, tg, n_pred, strip_wgs, o.J, h->tk_sync + 2, ra)));
+    if (rc) return rc;
+    h->run_done += (unsigned)nt;
+    h->seq_tag += (unsigned)nt;
+    h->seq_pub += 2u * kTickJ * (unsigned)nt;
+    h->seq_gather += (unsigned)nt; h->seq_pred += (unsigned)n_pred * (unsigned)nt;
+    if (nt & 1) { h->sidx ^= 1; h->cidx ^= 1; h->pidx ^= 1; }
+    h->state_epoch += (unsigned)nt;
+    h->host_seen_valid = false;
+    return NUSLAM_OK;
+}
+
 ObsArg inline_obs(double a, double b, int id, int cartesian)
 {
     ObsArg o;
@@ -1472,7 +1550,7 @@ void free_batch(nuslam_batch* h)
     if (h->st_host) (void)hipHostFree(h->st_host);
     if (h->st_tags) (void)hipHostFree(h->st_tags);
     void* ptrs[] = { h->state[0], h->state[1], h->ctrl[0], h->ctrl[1], h->Pbuf[0], h->Pbuf[1], h->cur_id, h->akey, h->dU, h->dV, h->tr,
-                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_tagK, h->tk_tagV, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
+                     h->stats, h->pose_err, h->da_mem, h->tk_plan, h->tk_K, h->tk_R, h->tk_V, h->tk_pub, h->tk_tagK, h->tk_tagV, h->tk_plan2, h->tk_ctrl4, h->tk_blk, h->tk_sync, h->tk_posmap, h->tk_KU, h->tk_RU, h->tk_SU, h->tk_run, h->tr_tw, h->tr_mx, h->tr_my, h->tr_ids, h->tr_truth, h->tr_scan, h->st_mx, h->st_my, h->st_ids, h->id_log,
                      h->wF };
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -2109,6 +2187,15 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         }
         rc = NUSLAM_OK;
     }
+    if (known_trace) {
+        rc = run_fused(h, t_begin, t_end, total_landmarks);
+        if (rc != kRunNotApplicable) {
+            h->id_log = saved_log;
+            if (!rc) h->last_tick = t_end - 1;
+            return rc;
+        }
+        rc = NUSLAM_OK;
+    }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
         tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
@@ -2151,10 +2238,12 @@ extern "C" int nuslam_debug_panels_clock(long long out[40])
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_panels_clock), sizeof(long long) * 40));
     return NUSLAM_OK;
 }
-extern "C" int nuslam_debug_front_timeline(long long out[16])
+extern "C" int nuslam_debug_front_timeline(long long out[32])
 {
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_front_tl), sizeof(long long) * 16));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(nuslam::g_front_tl), sizeof(long long) * 32));
+    const long long zero[32] = { 0 };                        // (the stamps that are maxima start over)
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(nuslam::g_front_tl), zero, sizeof(zero)));
     return NUSLAM_OK;
 }
 extern "C" int nuslam_debug_chain_clock(long long out[32])
@@ -2238,8 +2327,10 @@ int nuslam_batch_set_pairing(nuslam_batch_t* h, int enable)
 
 int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode)
 {
-    if (!h || mode < -1 || mode > 4) return NUSLAM_E_ARG;
+ if (!h || mode < -1 || mode > 5) return NUSLAM_E_ARG;
     { int lrc = lazy_flush(h); if (lrc) return lrc; }
+    h->run_fused = mode != 5;                      // 5: as 1 with every tick of a nuslam_batch_run a launch of its own (k_tick_fused)
+    if (mode == 5) mode = 1;
     h->front = mode != 3;                          // 3: as 1 with the chain and the strips as two launches (measurement)
     h->fuse_pass = mode != 3 && mode != 4;         // 4: as 1 with the pass over P as a launch of its own behind the front (round 3's default)
     h->tick_mode = (mode == 3 || mode == 4) ? 1 : mode;
