@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--tick-pipeline", action="store_true",
                     help="force the tick pipeline (chain + strips + ONE pass over P per tick) where the library's default "
                          "would pick the per-pair kernels (a single filter)")
-    ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2, 3, 4],
+    ap.add_argument("--tick-mode", type=int, default=None, choices=[0, 1, 2, 3, 4, 5],
                     help="nuslam_batch_set_tick_mode: 0 one pass over P per correction, 1 tick pipelines, 2 as 1 but unknown "
                          "association as one launch per marker instead of the resident round kernel")
     ap.add_argument("--pass-variant", type=int, default=None,
@@ -547,7 +547,7 @@ def main():
         bt.sync()
         t_at += K
     fused_launch = None
-    if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1) and not (args.per_correction or args.no_pairing
+    if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1, 5) and not (args.per_correction or args.no_pairing
                                                                                                  or args.deferred or args.overlap):
         # The default single-filter tick is ONE launch (k_tick_fused: predict || chain || strips || the rank-2m pass as workgroups of
         # one grid), whose duration is the serial chain's.  The HBM-bound kernel's own figures come from K more steps of the same
@@ -555,14 +555,18 @@ def main():
         fz_ms, fz_n = bt.profile_read(nh.K_TICK_CHAIN)
         rk_ms, rk_n = bt.profile_read(nh.K_TICK_RANK)
         if fz_n and not rk_n:
-            fused_launch = {"kernel": "k_tick_fused (predict || chain || strips || pass, csrc/ekf_fused.h)", "avg_launch_us": 1e3 * fz_ms / fz_n,
-                            "launches": fz_n}
+            per_launch = K // fz_n if fz_n < K else 1              # (a nuslam_batch_run of one filter is ONE launch: k_run_fused)
+            fused_launch = {"kernel": ("k_run_fused (the run's ticks in one launch: predict || chain || strips || pass, P resident in the pass "
+                                       "workgroups' registers between ticks, csrc/ekf_fused.h)" if per_launch > 1 else
+                                       "k_tick_fused (predict || chain || strips || pass, csrc/ekf_fused.h)"),
+                            "avg_launch_us": 1e3 * fz_ms / fz_n, "launches": fz_n, "ticks_per_launch": per_launch,
+                            "avg_tick_us": 1e3 * fz_ms / fz_n / per_launch}
             bt.set_tick_mode(4)
             bt.profile(True)
             bt.run(t_at, t_at + K)
             bt.sync()
             t_at += K
-            bt.set_tick_mode(1)
+            bt.set_tick_mode(1 if args.tick_mode is None else args.tick_mode)
     sweep_ms, sweep_n = bt.profile_read(nh.K_UPDATE)
     pair_ms, pair_n = bt.profile_read(nh.K_UPDATE2)
     pred_ms, pred_n = bt.profile_read(nh.K_PREDICT)
@@ -723,22 +727,31 @@ def main():
         if exact_pass:
             out["roofline"]["exact_pass_behind_it"] = exact_pass
         if fused_launch:
-            fused_launch["whole_launch_GBps"] = min_bytes / (1e-6 * fused_launch["avg_launch_us"]) / 1e9
-            fused_launch["note"] = ("the timed region runs the tick as this ONE launch: the pass's tile loads run under the serial chain, its "
-                                    "k-steps follow the strips, its stores close the launch; roofline.achieved / frac above are k_tick_rank's, "
-                                    "measured in %d more steps with the pass as a launch of its own (tick mode 4: same arithmetic, same bits)" % K)
+            if fused_launch["ticks_per_launch"] > 1:
+                fused_launch["note"] = ("the timed region runs each block of %d ticks as this ONE launch: the covariance is read once when the "
+                                        "launch begins and written once when it ends, in between it stays in the pass workgroups' accumulators "
+                                        "and a tick stores only the rows / columns of the next tick's index set; roofline.achieved / frac above "
+                                        "are k_tick_rank's, measured in %d more steps with the pass as a launch of its own (tick mode 4: same "
+                                        "arithmetic, same bits)" % (K, K))
+            else:
+                fused_launch["whole_launch_GBps"] = min_bytes / (1e-6 * fused_launch["avg_launch_us"]) / 1e9
+                fused_launch["note"] = ("the timed region runs the tick as this ONE launch: the pass's tile loads run under the serial chain, its "
+                                        "k-steps follow the strips, its stores close the launch; roofline.achieved / frac above are k_tick_rank's, "
+                                        "measured in %d more steps with the pass as a launch of its own (tick mode 4: same arithmetic, same bits)" % K)
             out["roofline"]["fused_launch"] = fused_launch
         # ... and the same bytes over the WHOLE tick (every kernel of it, launch gaps included): what the chip's HBM sees of a tick
         tick_s = dt_med / K
         out["roofline"]["whole_tick"] = {"bytes_per_step": min_bytes, "ms_per_step": 1e3 * tick_s, "GBps": min_bytes / tick_s / 1e9,
                                          "frac": min_bytes / tick_s / 1e9 / HBM_PEAK_GBS,
-                                         "note": "2*L^2*w*B / ms_per_step: the pass's bytes over the wall time of a whole tick"}
+                                         "note": "2*L^2*w*B / ms_per_step: the bytes a pass over P moves, over the wall time of a whole tick"
+                                                 + (" (algorithmic: in a one-launch run P stays on the chip between the ticks)"
+                                                    if fused_launch and fused_launch.get("ticks_per_launch", 1) > 1 else "")}
         kernel_us_fused = fused_launch
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}
         if kernel_us_fused:
-            out["kernel_us"]["tick_fused"] = kernel_us_fused["avg_launch_us"]
+            out["kernel_us"]["tick_fused"] = kernel_us_fused["avg_tick_us"]
             out["kernel_us"]["note"] = "tick_fused: the one launch of the timed region; tick_chain (k_tick_front) / tick_rank: the two launches of tick mode 4"
         if apply_n or rank_n:
             out["kernel_us"].update({"tick_chain": 1e3 * chain_ms / chain_n if chain_n else None,

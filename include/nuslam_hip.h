@@ -178,7 +178,11 @@ int nuslam_batch_size(const nuslam_batch_t* h, int* n_filters, int* len);
  * bcast != 0: the arrays describe ONE filter and every filter replays them. */
 int nuslam_batch_load_trace(nuslam_batch_t* h, int ticks, int m, const double* tw, const double* mx,
                             const double* my, const int* ids, int bcast);
-/* Run ticks [t_begin, t_end) of the resident trace on every filter (the loop body of slam.cpp:250-319). */
+/* Run ticks [t_begin, t_end) of the resident trace on every filter (the loop body of slam.cpp:250-319).
+ * ONE filter, known ids, no tick of the run able to hold a first sighting (the host proves it from the ids), the default tick mode:
+ * the run is ONE launch (csrc/ekf_fused.h, k_run_fused) -- the covariance is read when it begins, stays in the pass workgroups'
+ * registers from tick to tick (a tick stores only the rows / columns of the next tick's index set) and is complete in memory again
+ * when the call's work has finished, i.e. for every getter, copy and later call.  Same bits as a launch per tick. */
 int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landmarks);
 /* one filter's results (synchronise) */
 int nuslam_batch_get_state(nuslam_batch_t* h, int b, double* out, int len);
@@ -226,7 +230,9 @@ int nuslam_ekf_set_deferred(nuslam_ekf_t* h, int enable);
  * then ONE pass over the covariance that carries every tile through all corrections: 2 len^2 w bytes per tick.
  * For ONE filter the whole tick is one launch where it can be (csrc/ekf_fused.h: predict, chain, strips and the pass over the
  * covariance as workgroups of one grid -- the pass's tile loads run under the serial chain); mode 4: as 1 with the pass as a launch
- * of its own behind the front launch; mode 3: chain, strips and pass as three launches (measurement).  Same bits in 1, 3 and 4.
+ * of its own behind the front launch; mode 3: chain, strips and pass as three launches (measurement); mode 5: as 1 with every tick
+ * of a nuslam_batch_run a launch of its own (mode 1 runs the ticks of one filter's known-id run as ONE launch, see nuslam_batch_run).
+ * Same bits in 1, 3, 4 and 5.
  * mode 0: one pass per correction (or per pair, see nuslam_batch_set_pairing).  Same arithmetic on every element in
  * the same order: the two modes produce identical bits.  mode -1 (default): the library picks per handle.
  * Ticks with UNKNOWN association follow the same switch: mode 1 = tracked rows / columns / diagonal blocks of the

@@ -405,7 +405,8 @@ class Batch:
         _chk(lib().nuslam_batch_set_pairing(self._h, int(enable)), "batch_set_pairing")
 
     def set_tick_mode(self, mode):
-        """1 (default): known-id ticks as chain + panels + ONE pass over P; 0: one pass per correction / pair."""
+        """1 (default): known-id ticks as chain + panels + ONE pass over P (one filter: one launch per tick, a nuslam_batch_run one launch);
+        0: one pass per correction / pair; 3 / 4: the tick as three / two launches; 5: as 1 with a launch per tick in a run."""
         _chk(lib().nuslam_batch_set_tick_mode(self._h, int(mode)), "batch_set_tick_mode")
 
     def set_overlap(self, enable=True):
