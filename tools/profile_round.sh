@@ -17,6 +17,8 @@ step() { echo "== $*" | tee -a "$OUT/progress.log"; }
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
 step bench lines
 timeout -k 10 400 $B > "$OUT/bench_ekf1000.json" 2> "$OUT/bench_ekf1000.err" || exit 1
+timeout -k 10 200 $B --tick-mode 5 --cpu-seconds 0 > "$OUT/bench_ekf1000_launch_per_tick.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --steps 200 --cpu-seconds 0 --no-api > "$OUT/bench_ekf1000_200_ticks_per_run.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --tick-mode 4 --cpu-seconds 0 > "$OUT/bench_ekf1000_pass_as_second_launch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --tick-mode 3 --cpu-seconds 0 > "$OUT/bench_ekf1000_three_launches.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --pass-variant 2 --tick-mode 3 --no-overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_one_stream.json" 2>> "$OUT/bench.err" || exit 1
@@ -68,6 +70,7 @@ stats() {   # name, bench args...
     rm -rf "$OUT/prof_$name"
 }
 stats ekf1000 --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 || exit 1
+stats ekf1000_launch_per_tick --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 5 || exit 1
 stats ekf1000_pass_as_second_launch --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 4 || exit 1
 stats batch --workload batch --steps 20 --warmup 3 --blocks 2 --cpu-seconds 0 || exit 1
 stats da1000 --workload da1000 --steps 50 --warmup 5 --blocks 2 --cpu-seconds 0 || exit 1
@@ -84,10 +87,15 @@ pmc() {     # name, counter, bench args...
 PM="--steps 40 --warmup 10 --blocks 1 --cpu-seconds 0"
 pmc ekf1000 FETCH_SIZE $PM || exit 1
 pmc ekf1000 WRITE_SIZE $PM || exit 1
-# (the default run launches k_tick_fused in its timed steps and k_tick_rank in the extra tick-mode-4 block of the event pass)
+# (the default run launches k_run_fused in its timed blocks and k_tick_rank in the extra tick-mode-4 block of the event pass)
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_pmc_hbm_traffic.json" \
     "k_tick_rank<double" 40 2003 8 1 >> "$OUT/progress.log" 2>&1
-python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_fused_pmc_hbm_traffic.json" \
+# (k_run_fused: one launch per bench block -- warm-up 10 ticks, the timed block 40, the event pass 40: the last one is summarised)
+python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_FETCH_SIZE" "$OUT/pmc_ekf1000_WRITE_SIZE" "$OUT/ekf1000_run_fused_pmc_hbm_traffic.json" \
+    "k_run_fused<double" 1 2003 8 1 40 >> "$OUT/progress.log" 2>&1
+pmc ekf1000_tick FETCH_SIZE $PM --tick-mode 5 || exit 1
+pmc ekf1000_tick WRITE_SIZE $PM --tick-mode 5 || exit 1
+python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_tick_FETCH_SIZE" "$OUT/pmc_ekf1000_tick_WRITE_SIZE" "$OUT/ekf1000_fused_pmc_hbm_traffic.json" \
     "k_tick_fused<double" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
 PB="--workload batch --steps 6 --warmup 2 --blocks 1 --cpu-seconds 0"
 pmc batch FETCH_SIZE $PB || exit 1
