@@ -18,7 +18,7 @@ if [ "${SKIP_BENCH:-0}" != "1" ]; then
 step bench lines
 timeout -k 10 400 $B > "$OUT/bench_ekf1000.json" 2> "$OUT/bench_ekf1000.err" || exit 1
 timeout -k 10 200 $B --tick-mode 5 --cpu-seconds 0 > "$OUT/bench_ekf1000_launch_per_tick.json" 2>> "$OUT/bench.err" || exit 1
-timeout -k 10 200 $B --steps 200 --cpu-seconds 0 --no-api > "$OUT/bench_ekf1000_200_ticks_per_run.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 200 $B --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_ekf1000_driver_command.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --tick-mode 4 --cpu-seconds 0 > "$OUT/bench_ekf1000_pass_as_second_launch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --tick-mode 3 --cpu-seconds 0 > "$OUT/bench_ekf1000_three_launches.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 200 $B --pass-variant 2 --tick-mode 3 --no-overlap --cpu-seconds 0 > "$OUT/bench_ekf1000_exact_chain_one_stream.json" 2>> "$OUT/bench.err" || exit 1
