@@ -88,6 +88,7 @@ def parse():
     ap.add_argument("--pass-variant", type=int, default=None,
                     help="nuslam_batch_set_pass_variant: 0 (default) the rank-2m pass on the matrix cores, 1 / 2 the exact chain "
                          "(plain / two-unit kernel), 10 + k the rank-2m pass with tile shape k")
+    ap.add_argument("--interleave", type=int, default=None, help="nuslam_batch_set_interleave: groups of filters on streams of their own (1..4; 10 + G: without the passes taking turns)")
     ap.add_argument("--plain-pass", action="store_true", help="nuslam_batch_set_pass_variant(1): the exact chain, plain kernel")
     ap.add_argument("--dense-random-f", action="store_true",
                     help="ekf5000: propagate with a fixed dense random Jacobian instead of the reference's A = I + B formed on the "
@@ -508,6 +509,8 @@ def main():
         bt.set_pass_variant(1)
     if args.pass_variant is not None:
         bt.set_pass_variant(args.pass_variant)
+    if args.interleave is not None:
+        bt.set_interleave(args.interleave)
     if args.no_overlap:
         bt.set_overlap(False)
     if args.overlap:
@@ -542,10 +545,17 @@ def main():
     if not in_region:
         # kernel durations: the next K steps of the same trace, every dispatch bracketed by its own HIP events
         # on the handle's stream (hipExtLaunchKernelGGL start/stop events)
+        # (a large batch's timed ticks run as groups of filters on streams of their own, one group's pass beside the other's chain and
+        # strips: the kernels' own durations are taken with the batch as ONE group, every kernel alone on the chip)
+        grouped_batch = args.workload == "batch" and B >= 512 and args.interleave in (None, -1)
+        if grouped_batch:
+            bt.set_interleave(1)
         bt.profile(True)
         bt.run(t_at, t_at + K)
         bt.sync()
         t_at += K
+        if grouped_batch:
+            bt.set_interleave(-1)
     fused_launch = None
     if known and B == 1 and args.workload == "ekf1000" and args.tick_mode in (None, 1, 5) and not (args.per_correction or args.no_pairing
                                                                                                  or args.deferred or args.overlap):
@@ -747,6 +757,10 @@ def main():
                                                  + (" (algorithmic: in a one-launch run P stays on the chip between the ticks)"
                                                     if fused_launch and fused_launch.get("ticks_per_launch", 1) > 1 else "")}
         kernel_us_fused = fused_launch
+        if args.workload == "batch" and B >= 512 and args.interleave in (None, -1):
+            out["roofline"]["note_groups"] = ("the timed region runs the batch as 2 groups of filters on 2 streams (nuslam_batch_set_interleave default: one "
+                                              "group's pass beside the other's chain and strips); avg_launch_us / frac and kernel_us are each kernel ALONE, "
+                                              "from %d more steps with the batch as one group" % K)
         out["kernel_us"] = {"update": 1e3 * sweep_ms / sweep_n,
                             "predict": 1e3 * pred_ms / max(pred_n, 1),
                             "associate": 1e3 * asso_ms / max(asso_n, 1) if asso_n else None}

@@ -31,8 +31,8 @@ extern "C" {
  *    _CAPACITY; nuslam_batch_set_pass_variant selects between the rank-2m pass and the exact chain; NUSLAM_K_TICK_RANK */
 /* 3: nuslam_ekf_predict / _init_landmark / _update of a single filter are RECORDED and applied tick by tick (see "Lazy ticks"
  *    below; nuslam_ekf_set_lazy); nuslam_ekf_tick_ex; nuslam_batch_inject_fault; a poisoned handle (NUSLAM_E_SYNC) comes back only
- *    when every filter has been restored; RETIRED: nuslam_batch_set_interleave (groups of filters on streams of their own: measured
- *    neutral) and the four-corrections-per-pass kernel behind nuslam_batch_set_pairing(h, 4) (slower than pairs).  (Also since 2,
+ *    when every filter has been restored; nuslam_batch_set_interleave is now ON by default for large batches (see there); RETIRED:
+ *    the four-corrections-per-pass kernel behind nuslam_batch_set_pairing(h, 4) (slower than pairs).  (Also since 2,
  *    not listed then: nuslam_sim_params grew by `fov` and `min_range` -- a caller compiled against the version-1 struct must be
  *    rebuilt.) */
 #define NUSLAM_HIP_ABI_VERSION 3
@@ -252,6 +252,13 @@ int nuslam_batch_set_tick_mode(nuslam_batch_t* h, int mode);
  * rank-2m pass (one stream is the faster order there), on for one filter / off for batches with the exact chain.
  * Should a hand-off expire all the same (NUSLAM_E_SYNC), the handle refuses further ticks until it is restored. */
 int nuslam_batch_set_overlap(nuslam_batch_t* h, int enable);
+/* nuslam_batch_run of a LARGE batch on a known-id trace: the filters run as `groups` (1..4) groups, each on a stream of its own, the
+ * groups' passes over the covariance taking turns, so that one group's HBM-bound pass runs beside the other groups' latency-bound
+ * chains and their strips.  Same kernels on the same per-filter data: same bits for every group count.  groups < 0 (default): 2
+ * groups for 512 filters and more, else one (1024 x N = 200 on one MI355X: 2 groups 728 us per tick, one 781, 3: 752, 4: 799).
+ * 10 + G: G groups whose passes do not take turns (measurement).  Every call that looks at the handle afterwards waits for all of
+ * its streams. */
+int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups);
 /* How a tick pipeline's ONE pass over the covariance applies the round's corrections.
  *   0 (default)  as a rank-2m update on the matrix cores: update()'s P <- (I - K H) P (slam_library.cpp:279) re-associated
  *                as P - K (H P), all corrections of the round in one v_mfma_f64 accumulation per tile -- 2 FMAs per element

@@ -143,6 +143,16 @@ struct nuslam_batch {
     int seq_chain = 0, seq_next = 0;                   // the counters' values after everything enqueued so far
     hipEvent_t ov_start = nullptr;
     std::vector<hipEvent_t> ov_events;
+    // Groups (nuslam_batch_set_interleave): the known-id ticks of a LARGE batch's resident trace run as G groups of filters, each on a
+    // stream of its own, the groups' passes over P taking turns: one group's HBM-bound pass then runs beside the other group's
+    // latency-bound chain and its strips.  Same kernels on the same per-filter data: same bits.  -1 (default): 2 groups for 512
+    // filters and more (1024 x N = 200: 728 us per tick against 781), else 1.
+    int groups = -1;
+    hipStream_t gstream[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t gev[4] = { nullptr, nullptr, nullptr, nullptr }, gev0 = nullptr;
+    hipEvent_t gpass[4] = { nullptr, nullptr, nullptr, nullptr };   // group g's last pass over P is done
+    bool gpass_set[4] = { false, false, false, false };
+    int group_ring = 1;        // the groups' passes take turns (measurement: nuslam_batch_set_interleave(h, 10 + G) lets them run free)
     bool pairing = true;       // k_update2 for consecutive plain corrections of a known-id tick
     std::vector<int> host_seen;   // host mirror of every filter's `seen`; valid while only known-id calls were made
     bool host_seen_valid = true;
@@ -867,6 +877,119 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
     return NUSLAM_OK;
 }
 
+// ---- groups of filters on streams of their own
+int group_count(const nuslam_batch* h)
+{
+    int g = h->groups < 0 ? (h->B >= 512 ? 2 : 1) : h->groups;        // (measured at 1024 x N = 200: 2 groups 728 us per tick, 1: 781, 3: 752, 4: 799)
+    if (g > 4) g = 4;
+    if (g > h->B) g = h->B;
+    return g < 1 ? 1 : g;
+}
+Sub group_of(nuslam_batch* h, int g, int G)
+{
+    const int g0 = (int)((long long)h->B * g / G), g1 = (int)((long long)h->B * (g + 1) / G);
+    return Sub{ g0, g1 - g0, g == 0 ? h->stream : h->gstream[g] };
+}
+int ensure_groups(nuslam_batch* h, int G)
+{
+    for (int g = 1; g < G; ++g)
+        if (!h->gstream[g]) {
+            HIPCHK(hipStreamCreateWithFlags(&h->gstream[g], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&h->gev[g], hipEventDisableTiming));
+        }
+    if (!h->gev0) HIPCHK(hipEventCreateWithFlags(&h->gev0, hipEventDisableTiming));
+    for (int g = 0; g < G; ++g)
+        if (!h->gpass[g]) HIPCHK(hipEventCreateWithFlags(&h->gpass[g], hipEventDisableTiming));
+    return NUSLAM_OK;
+}
+// the group streams start behind everything the handle's stream holds / the handle's stream goes on behind all of them
+int groups_fork(nuslam_batch* h, int G)
+{
+    HIPCHK(hipEventRecord(h->gev0, h->stream));
+    for (int g = 1; g < G; ++g) HIPCHK(hipStreamWaitEvent(h->gstream[g], h->gev0, 0));
+    for (int g = 0; g < 4; ++g) h->gpass_set[g] = false;
+    return NUSLAM_OK;
+}
+int groups_join(nuslam_batch* h, int G)
+{
+    for (int g = 1; g < G; ++g) {
+        HIPCHK(hipEventRecord(h->gev[g], h->gstream[g]));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->gev[g], 0));
+    }
+    return NUSLAM_OK;
+}
+
+// One known-id tick of a large batch as G groups of filters on G streams: predict, chain, strips and the pass of each group are
+// enqueued on the group's own stream, so the groups' phases slide against each other on the chip.  Same kernels, same per-filter
+// data as the ungrouped tick: same bits.  (The caller forks / joins the streams around a run of such ticks.)
+int do_tick_grouped(nuslam_batch* h, int G, const TwistArg& tw, const ObsArg& base, int m, int total, const int* host_ids,
+                    const int* pf_ids, long long pf_stride)
+{
+    if (h->poisoned) return NUSLAM_E_SYNC;
+    h->last_tick = -1;
+    { int erc = ensure_tick_buffers(h); if (erc) return erc; }
+    int rc = NUSLAM_OK;
+    {   // ---- predict (slam_library.cpp:65-148)
+        const View v = h->view();
+        for (int g = 0; g < G && !rc; ++g) {
+            const Sub sb = group_of(h, g, G);
+            TwistArg twg = tw;
+            if (twg.tw) twg.off += (long long)sb.g0 * twg.stride;
+            dim3 grid((h->ld + 255) / 256, 1, sb.Bg), block(256);
+            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_PREDICT, k_predict<T, false>, grid, block, 0, sub_view(v, sb), twg,
+                                          filt<T>(h->P(), h, sb), h->predict_bookkeeping, (T*)nullptr)));
+        }
+        if (rc) return rc;
+        h->sidx ^= 1; h->state_epoch++;
+        h->cidx ^= 1;
+    }
+    const bool may_init = tick_may_init_all(h, host_ids, pf_ids, pf_stride, m, total);
+    double* vbuf = h->pass_mode == 0 ? h->tk_V : nullptr;
+    const int rank_ok = h->pass_mode != 0 ? 0 : (may_init ? 1 : 2);
+    for (int i0 = 0; i0 < m; i0 += kTickJ) {
+        const TickObs o = make_tick_obs(h, base, i0, m, host_ids, nullptr, nullptr);
+        const View v = h->view();
+        for (int g = 0; g < G && !rc; ++g) {
+            const Sub sb = group_of(h, g, G);
+            const View w = sub_view(v, sb);
+            TickObs og = o;
+            og.off += (long long)sb.g0 * og.stride;                     // (a broadcast trace has stride 0)
+            TickStep* pl = h->tk_plan + (size_t)sb.g0 * kTickJ;
+            DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_CHAIN, k_tick_chain<T, false>, dim3(sb.Bg), dim3(256), 0, w, og, total,
+                                          (const T*)filt<T>(h->P(), h, sb), pl, TickCarry{}, (int*)nullptr, (int*)nullptr)));
+            if (rc) break;
+            double* Kp = h->tk_K + (size_t)sb.g0 * kTickJ * 2 * h->ld;
+            double* Rp = (h->pass_mode == 0 && !may_init) ? nullptr : h->tk_R + (size_t)sb.g0 * kTickJ * 5 * h->ld;
+            double* Vp = vbuf ? vbuf + (size_t)sb.g0 * kTickJ * 2 * h->ld : nullptr;
+            if (rank_ok == 2 && !Rp && Vp && h->strips_lane && (long long)((h->ld + 63) / 64) * sb.Bg > 4 * h->n_cu)
+                DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_strips_lane<T>, dim3(8 * ((sb.Bg + 7) / 8) * ((h->ld + 63) / 64)), dim3(128), 0,
+                                              w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Vp)));
+            else
+                DISPATCH_T(h, rc = (launch_on(h, sb.st, NUSLAM_K_TICK_PANELS, k_tick_panels<T, 64>, dim3((h->ld + 63) / 64, sb.Bg), dim3(512),
+                                              sizeof(double) * (rank_ok == 2 ? kPlanHeadWords : kPlanExactWords) * (size_t)og.J, w, og, (const T*)filt<T>(h->P(), h, sb), (const TickStep*)pl, Kp, Rp, Vp,
+                                              (const int*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, rank_ok)));
+            if (rc) break;
+            // The passes take turns: group g's pass starts when group g-1's (for group 0: the last group's of the previous round) has
+            // ended.  Left to themselves the groups run in step -- pass beside pass, strips beside strips --; with the passes in a ring one
+            // group's HBM-bound pass runs beside the other groups' chains and strips.
+            const int prev = (g + G - 1) % G;
+            if (h->group_ring && h->gpass_set[prev]) HIPCHK(hipStreamWaitEvent(sb.st, h->gpass[prev], 0));
+            rc = launch_pass(h, v, og.J, h->tk_plan, false, may_init, sb);
+            if (rc) break;
+            if (h->group_ring) {
+                HIPCHK(hipEventRecord(h->gpass[g], sb.st));
+                h->gpass_set[g] = true;
+            }
+        }
+        if (rc) return rc;
+        h->sidx ^= 1; h->state_epoch++;
+        h->cidx ^= 1;
+        h->pidx ^= 1;
+    }
+    h->host_seen_valid = false;
+    return NUSLAM_OK;
+}
+
 // nuslam_batch_run, ticks [t0, t1) of ONE filter's resident known-id trace, as ONE launch (k_run_fused, ekf_fused.h): the covariance
 // stays in the pass workgroups' registers between the ticks.  kRunNotApplicable: this handle / this run takes a launch per tick
 // (anything but the default known-id pipeline, a tick that may hold a first sighting, ids the host does not have).
@@ -1546,6 +1669,13 @@ void free_batch(nuslam_batch* h)
         (void)serve_end(h);
     }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int g = 1; g < 4; ++g) {
+        if (h->gstream[g]) { (void)hipStreamSynchronize(h->gstream[g]); (void)hipStreamDestroy(h->gstream[g]); }
+        if (h->gev[g]) (void)hipEventDestroy(h->gev[g]);
+    }
+    if (h->gev0) (void)hipEventDestroy(h->gev0);
+    for (int g = 0; g < 4; ++g)
+        if (h->gpass[g]) (void)hipEventDestroy(h->gpass[g]);
     if (h->srv.mail) (void)hipHostFree(h->srv.mail);
     if (h->st_host) (void)hipHostFree(h->st_host);
     if (h->st_tags) (void)hipHostFree(h->st_tags);
@@ -1613,6 +1743,8 @@ int sync_all_streams(nuslam_batch* h)
 {
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->stream2 && h->stream2 != h->stream) HIPCHK(hipStreamSynchronize(h->stream2));
+    for (int g = 1; g < 4; ++g)
+        if (h->gstream[g]) HIPCHK(hipStreamSynchronize(h->gstream[g]));
     return NUSLAM_OK;
 }
 // The rank-2m pass reads all 32 factor rows of a filter's K / V strips every round and masks the unused ones by multiplication:
@@ -2196,6 +2328,15 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         }
         rc = NUSLAM_OK;
     }
+    // a large batch on a known-id trace: G groups of filters on G streams (do_tick_grouped)
+    const int G = group_count(h);
+    const bool grouped = G > 1 && known_trace && h->tr_m >= 1 && tick_pipeline_pays(h, h->tr_m) && !h->deferred && !h->dense_predict &&
+                         !front_fits(h, false) && t_end > t_begin && (!h->h_ids.empty() || !h->h_ids_pf.empty());
+    if (grouped) {
+        rc = ensure_groups(h, G);
+        if (!rc) rc = ensure_tick_buffers(h);
+        if (!rc) rc = groups_fork(h, G);
+    }
     for (int t = t_begin; t < t_end && !rc; ++t) {
         TwistArg tw;
         tw.tw = h->tr_tw; tw.stride = h->tr_bcast ? 0 : (long long)h->tr_ticks * 2; tw.off = (long long)t * 2;
@@ -2207,9 +2348,13 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         o.a0 = o.b0 = 0.0; o.id0 = 0; o.cartesian = 1; o.log_slot = -1;
         const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data() + (size_t)t * h->tr_m;
         const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data() + (size_t)t * h->tr_m;
-        rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
-                     (long long)h->tr_ticks * h->tr_m);
+        if (grouped)
+            rc = do_tick_grouped(h, G, tw, o, h->tr_m, total_landmarks, hid, pfid, (long long)h->tr_ticks * h->tr_m);
+        else
+            rc = do_tick(h, tw, o, h->tr_m, h->tr_ids != nullptr && !h->tr_presence_only, total_landmarks, hid, nullptr, nullptr, pfid,
+                         (long long)h->tr_ticks * h->tr_m);
     }
+    if (grouped) { int jrc = groups_join(h, G); if (!rc) rc = jrc; }
     h->id_log = saved_log;
     if (!rc && t_end > t_begin) h->last_tick = t_end - 1;
     return rc;
@@ -2347,6 +2492,15 @@ int nuslam_batch_set_pass_variant(nuslam_batch_t* h, int variant)
     h->pass_mode = variant;
     h->rank_tile = 0;
     h->apply_units = variant != 1;
+    return NUSLAM_OK;
+}
+
+int nuslam_batch_set_interleave(nuslam_batch_t* h, int groups)
+{
+    if (!h || (groups > 4 && (groups < 11 || groups > 14))) return NUSLAM_E_ARG;
+    h->group_ring = groups < 10;                   // 10 + G: G groups whose passes do not take turns (measurement)
+    if (groups >= 10) groups -= 10;
+    h->groups = groups < 0 ? -1 : (groups < 1 ? 1 : groups);
     return NUSLAM_OK;
 }
 

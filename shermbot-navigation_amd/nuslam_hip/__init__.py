@@ -72,6 +72,7 @@ SYMBOLS = [
     ("nuslam_batch_set_pairing", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_tick_mode", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_overlap", C.c_int, [_vp, C.c_int]),
+    ("nuslam_batch_set_interleave", C.c_int, [_vp, C.c_int]),
     ("nuslam_batch_set_pass_variant", C.c_int, [_vp, C.c_int]),
     ("nuslam_circle_fit_batch", C.c_int, [C.c_int, _ip, _dp, _dp, _dp, _dp, _dp, _ip, _ip, _dp, C.c_int, _dp]),
     ("nuslam_batch_profile", C.c_int, [_vp, C.c_int]),
@@ -408,6 +409,10 @@ class Batch:
         """1 (default): known-id ticks as chain + panels + ONE pass over P (one filter: one launch per tick, a nuslam_batch_run one launch);
         0: one pass per correction / pair; 3 / 4: the tick as three / two launches; 5: as 1 with a launch per tick in a run."""
         _chk(lib().nuslam_batch_set_tick_mode(self._h, int(mode)), "batch_set_tick_mode")
+
+    def set_interleave(self, groups):
+        """groups of filters on streams of their own in nuslam_batch_run (1..4; < 0: the library's default)."""
+        _chk(lib().nuslam_batch_set_interleave(self._h, int(groups)), "batch_set_interleave")
 
     def set_overlap(self, enable=True):
         """True / False / None (library default); 2: the test hook (second stream = the handle's own)."""

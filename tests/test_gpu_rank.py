@@ -176,6 +176,36 @@ def test_batch_strips_a_lane_per_index_same_bits_as_the_quads(hip, n, B, dtype):
         assert np.array_equal(s0, s1) and np.array_equal(p0, p1)
 
 
+@pytest.mark.parametrize("n,B,dtype", [(200, 600, 0), (30, 1300, 1)])
+def test_groups_of_filters_on_their_own_streams_same_bits(hip, n, B, dtype):
+    """nuslam_batch_run of a large batch as 1, 2, 3, 4 groups of filters on streams of their own (the default picks by size): the same
+    kernels on the same per-filter data -- identical state, covariance and statistics; a getter between two runs waits for every stream."""
+    m, T, K = 16, 6, 8
+    lm = synth.make_landmarks(n)
+    traces = [synth.make_trace(n, T, m, seed=700 + k, landmarks=lm, **EXACT_WHEELS) for k in range(K)]
+    pick = np.arange(B) % K
+    tw = np.stack([t.tw[:, :2] for t in traces])[pick]; mx = np.stack([t.mx for t in traces])[pick]
+    my = np.stack([t.my for t in traces])[pick]; ids = np.stack([t.ids for t in traces])[pick].copy()
+    ids[1::3, 1, 4] = -1
+    bx, by, wid = synth.warmup_observations(lm)
+    out = []
+    for groups in (1, 2, 3, 4, -1, 12):
+        bt = hip.Batch(B, n, Q, R, dtype=dtype)
+        bt.set_interleave(groups)
+        bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
+        bt.run(0, 1)
+        bt.load_trace(tw, mx, my, ids)
+        bt.run(0, 3)
+        mid = bt.state(B - 1).copy()                   # (a filter of the last group, in mid-run)
+        bt.run(3, T)
+        assert bt.status() == (-1, 0)
+        out.append((mid, bt.stats(), [(bt.state(k), bt.cov(k)) for k in range(0, B, max(1, B // 48))]))
+    for o in out[1:]:
+        assert np.array_equal(out[0][0], o[0]) and np.array_equal(out[0][1], o[1])
+        for (s0, p0), (s1, p1) in zip(out[0][2], o[2]):
+            assert np.array_equal(s0, s1) and np.array_equal(p0, p1)
+
+
 @pytest.mark.parametrize("mode", [1, 2], ids=["resident-round", "launch-per-marker"])
 def test_unknown_association_same_verdicts_covariance_within_rounding(hip, mode):
     """associateLandmark in front of every correction (slam_library.cpp:188-253): the verdicts are threshold decisions on
