@@ -475,6 +475,8 @@ def main():
             ekf.use_dense_predict(2)
     else:
         bt = nh.Batch(B, n, Q, R, dtype=dtype, device=dev)
+        if args.interleave is not None:
+            bt.set_interleave(args.interleave)
         # initialise every filter's map with one resident warm-up tick of n observations
         bt.load_trace(np.zeros((1, 2)), bx[None, :], by[None, :], wid[None, :], bcast=True)
         bt.run(0, 1)

@@ -27,6 +27,7 @@ timeout -k 10 200 $B --per-correction --cpu-seconds 0 > "$OUT/bench_ekf1000_pair
 timeout -k 10 200 $B --no-pairing --cpu-seconds 0 > "$OUT/bench_ekf1000_per_correction.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 > "$OUT/bench_batch.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 --pass-variant 1 > "$OUT/bench_batch_exact_chain.json" 2>> "$OUT/bench.err" || exit 1
+timeout -k 10 300 $B --workload batch --steps 50 --warmup 10 --interleave 1 --cpu-seconds 0 > "$OUT/bench_batch_one_group.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 400 $B --workload da1000 --steps 100 --warmup 10 > "$OUT/bench_da1000.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload da1000 --steps 100 --warmup 10 --tick-mode 2 --cpu-seconds 0 > "$OUT/bench_da1000_launch_per_marker.json" 2>> "$OUT/bench.err" || exit 1
 timeout -k 10 300 $B --workload ekf5000 > "$OUT/bench_ekf5000.json" 2>> "$OUT/bench.err" || exit 1
@@ -72,7 +73,8 @@ stats() {   # name, bench args...
 stats ekf1000 --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 || exit 1
 stats ekf1000_launch_per_tick --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 5 || exit 1
 stats ekf1000_pass_as_second_launch --steps 200 --warmup 20 --blocks 3 --cpu-seconds 0 --tick-mode 4 || exit 1
-stats batch --workload batch --steps 20 --warmup 3 --blocks 2 --cpu-seconds 0 || exit 1
+# (the batch as ONE group: every kernel alone on the chip, as in the bench line's own event pass; the default runs it as two groups)
+stats batch --workload batch --steps 20 --warmup 3 --blocks 2 --cpu-seconds 0 --interleave 1 || exit 1
 stats da1000 --workload da1000 --steps 50 --warmup 5 --blocks 2 --cpu-seconds 0 || exit 1
 stats ekf5000 --workload ekf5000 --cpu-seconds 0 || exit 1
 
@@ -97,7 +99,7 @@ pmc ekf1000_tick FETCH_SIZE $PM --tick-mode 5 || exit 1
 pmc ekf1000_tick WRITE_SIZE $PM --tick-mode 5 || exit 1
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_ekf1000_tick_FETCH_SIZE" "$OUT/pmc_ekf1000_tick_WRITE_SIZE" "$OUT/ekf1000_fused_pmc_hbm_traffic.json" \
     "k_tick_fused<double" 80 2003 8 1 >> "$OUT/progress.log" 2>&1
-PB="--workload batch --steps 6 --warmup 2 --blocks 1 --cpu-seconds 0"
+PB="--workload batch --steps 6 --warmup 2 --blocks 1 --cpu-seconds 0 --interleave 1"
 pmc batch FETCH_SIZE $PB || exit 1
 pmc batch WRITE_SIZE $PB || exit 1
 python3 "$ROOT/tools/summarize_pmc.py" "$OUT/pmc_batch_FETCH_SIZE" "$OUT/pmc_batch_WRITE_SIZE" "$OUT/batch_pmc_hbm_traffic.json" \
