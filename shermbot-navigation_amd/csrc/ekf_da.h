@@ -31,6 +31,7 @@ namespace nuslam {
 constexpr int kDaSlots = 64;     // index slots of a workgroup: slots 0..2 = the pose indices (carried by EVERY workgroup,
 constexpr int kDaOwn = 60;       // stored by workgroup 0), slots 3..62 = 60 own indices = 30 landmarks, slot 63 idle
 constexpr int kDaLm = kDaOwn / 2;
+constexpr int kDaSlotStride = 16; // 8-byte words between two workgroups' key slots: a 128-byte line each
 
 struct DaBuf {
     double* TR[2];   // [B][3][ld]
@@ -43,7 +44,7 @@ struct DaBuf {
     int nwg;
     // resident round only:
     double* AP[2];          // [B][n][16]  what associateLandmark formed for a MATCHING candidate: H (10), psi^-1 (4), z_hat (2)
-    long long* keyt;        // [B][kTickJ][nwg]  (tag << 32) | key: the key slot doubles as the workgroup's arrival flag
+    long long* keyt;        // [B][kTickJ][nwg][kDaSlotStride]  (tag << 32) | key: the key slot doubles as the workgroup's arrival flag
     long long* fwd;         // [B][8]  served rounds: the command workgroup 0 took from the host's mailbox, for the other workgroups
 };
 
@@ -1185,15 +1186,15 @@ __global__ __launch_bounds__(256) void k_da_round(View v, TickObs o, int total_l
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int tag = round_tag + st + 2;
-            long long* slots = d.keyt + ((size_t)b * kTickJ + st + 1) * nwg;
+            long long* slots = d.keyt + ((size_t)b * kTickJ + st + 1) * nwg * kDaSlotStride;
             if (wave == 0) {
-                if (lane == 0) st_agent(slots + wg, ((long long)tag << 32) | (unsigned)meet_sh[0]);
+                if (lane == 0) st_agent(slots + (size_t)wg * kDaSlotStride, ((long long)tag << 32) | (unsigned)meet_sh[0]);
                 int kmin = kNoKey, ok = 1;
                 for (int i = lane; i < nwg; i += 64) {
                     long long w = 0;
                     int got = 0;
                     for (int it = 0; it < (1 << 20); ++it) {
-                        w = ld_agent(slots + i);
+                        w = ld_agent(slots + (size_t)i * kDaSlotStride);
                         if ((int)(w >> 32) == tag) { got = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }

@@ -726,7 +726,7 @@ int ensure_da_buffers(nuslam_batch* h)
     const int nwg = (h->ld - 3 + kDaOwn - 1) / kDaOwn > 0 ? (h->ld - 3 + kDaOwn - 1) / kDaOwn : 1;
     // one allocation: 2 x (TR, TC) [B][3][ld], 2 x TD [B][4][n], 2 x DS [B][ld], Z [B][2][kTickJ]; then the int arrays
     // ... AP 2 x [B][n][16], keyt [B][kTickJ][nwg] (8-byte words)
-    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ + 2 * B * n * 16 + B * kTickJ * (size_t)nwg + 8 * B;
+    const size_t nd = 2 * (2 * B * 3 * ld) + 2 * B * 4 * n + 2 * B * ld + B * 2 * kTickJ + 2 * B * n * 16 + B * kTickJ * (size_t)nwg * kDaSlotStride + 8 * B;
     const size_t ni = 2 * B * C_WORDS + B * kTickJ * (size_t)nwg;
     HIPCHK(hipMalloc(&h->da_mem, nd * sizeof(double) + ni * sizeof(int)));
     HIPCHK(hipMemsetAsync(h->da_mem, 0, nd * sizeof(double) + ni * sizeof(int), h->stream));
@@ -737,7 +737,7 @@ int ensure_da_buffers(nuslam_batch* h)
     for (int k = 0; k < 2; ++k) { h->da.DS[k] = p; p += B * ld; }
     h->da.Z = p; p += B * 2 * kTickJ;
     for (int k = 0; k < 2; ++k) { h->da.AP[k] = p; p += B * n * 16; }
-    h->da.keyt = (long long*)p; p += B * kTickJ * (size_t)nwg;
+    h->da.keyt = (long long*)p; p += B * kTickJ * (size_t)nwg * kDaSlotStride;
     h->da.fwd = (long long*)p; p += 8 * B;
     int* q = (int*)p;
     for (int k = 0; k < 2; ++k) { h->da.DC[k] = q; q += B * C_WORDS; }
@@ -796,6 +796,14 @@ bool front_fits(const nuslam_batch* h, bool with_predict)
     return h->front && per_filter * h->B <= h->n_cu;
 }
 
+// k_tick_fused / k_run_fused: every workgroup of the grid must be resident at once (two waves per SIMD: two workgroups per CU)
+bool fused_fits(const nuslam_batch* h)
+{
+    int n_pass = 0;
+    DISPATCH_T(h, n_pass = FusedTile<T>::blocks(h->ld, h->L));
+    return 1 + (h->ld + 255) / 256 + (h->ld + 31) / 32 + n_pass <= 2 * h->n_cu;
+}
+
 // fused_predict != null: no predict kernel ran for this tick -- its predict rides in the first round's k_tick_front launch
 int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const int* host_ids, const double* host_mx,
                    const double* host_my, const int* pf_ids, long long pf_stride, const TwistArg* fused_predict = nullptr,
@@ -834,7 +842,7 @@ int do_tick_rounds(nuslam_batch* h, const ObsArg& base, int m, int total, const 
             if (with_predict) pub.tw = *fused_predict;
             else { pub.tw.tw = nullptr; pub.tw.stride = pub.tw.off = 0; pub.tw.dth0 = pub.tw.dx0 = 0.0; }
             // ONE filter, the rank-2m pass, no first sighting possible: the pass rides in the same launch (ekf_fused.h)
-            const bool fused = h->fuse_pass && h->B == 1 && h->pass_mode == 0 && h->rank_tile == 0 && !may_init;
+            const bool fused = h->fuse_pass && h->B == 1 && h->pass_mode == 0 && h->rank_tile == 0 && !may_init && fused_fits(h);
             if (fused) {
                 h->seq_tag += 1u;
                 if (h->seq_tag == 0u) h->seq_tag = 1u;
@@ -999,7 +1007,7 @@ int run_fused(nuslam_batch* h, int t0, int t1, int total)
     const int nt = t1 - t0, m = h->tr_m;
     if (!(h->run_fused && h->fuse_pass && h->front && h->B == 1 && h->pass_mode == 0 && h->rank_tile == 0 && nt >= 2 && m >= 1 && m <= kTickJ &&
           h->tr_ids && !h->tr_presence_only && tick_pipeline_pays(h, m) && !h->deferred && !h->dense_predict && h->predict_bookkeeping &&
-          front_fits(h, true) && !h->id_log))
+          front_fits(h, true) && fused_fits(h) && !h->id_log))
         return kRunNotApplicable;
     const int* hid = h->h_ids.empty() ? nullptr : h->h_ids.data();
     const int* pfid = h->h_ids_pf.empty() ? nullptr : h->h_ids_pf.data();
