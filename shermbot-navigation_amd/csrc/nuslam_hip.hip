@@ -2328,13 +2328,23 @@ int nuslam_batch_run(nuslam_batch_t* h, int t_begin, int t_end, int total_landma
         rc = NUSLAM_OK;
     }
     if (known_trace) {
-        rc = run_fused(h, t_begin, t_end, total_landmarks);
-        if (rc != kRunNotApplicable) {
-            h->id_log = saved_log;
-            if (!rc) h->last_tick = t_end - 1;
-            return rc;
+        // one filter: the run as ONE launch (k_run_fused) -- in stretches of at most kRunMaxTicks ticks (~0.2 s of one kernel), and tick
+        // by tick from the first stretch that does not qualify (a possible first sighting)
+        constexpr int kRunMaxTicks = 4096;
+        bool ran = false;
+        while (t_begin < t_end) {
+            const int t1 = t_end - t_begin <= kRunMaxTicks + 1 ? t_end : t_begin + kRunMaxTicks;
+            rc = run_fused(h, t_begin, t1, total_landmarks);
+            if (rc == kRunNotApplicable) { rc = NUSLAM_OK; break; }
+            if (rc) { h->id_log = saved_log; return rc; }
+            t_begin = t1;
+            ran = true;
         }
-        rc = NUSLAM_OK;
+        if (ran && t_begin >= t_end) {
+            h->id_log = saved_log;
+            h->last_tick = t_end - 1;
+            return NUSLAM_OK;
+        }
     }
     // a large batch on a known-id trace: G groups of filters on G streams (do_tick_grouped)
     const int G = group_count(h);

@@ -101,3 +101,25 @@ def test_run_as_one_launch_against_the_oracle(hip):
     ep = float((np.abs(f.cov - o.cov) / np.maximum(np.abs(o.cov), 1e-12 * np.abs(o.cov).max())).max())
     print("one-launch run vs oracle, tick %d: state %.2e cov %.2e" % (T, es, ep))
     assert es < 1e-6 and ep < 1e-6 and f.seen == o.seen
+
+
+def test_a_long_run_goes_in_stretches(hip):
+    """More ticks than one launch takes (4096): the run goes in stretches of one launch each -- same bits as a launch per tick."""
+    n, m, T = 40, 16, 4100
+    lm = synth.make_landmarks(n)
+    tr = synth.make_trace(n, 60, m, landmarks=lm, straight_every=4, **EXACT_WHEELS)
+    reps = (T + 59) // 60
+    tw = np.tile(tr.tw[:, :2], (reps, 1))[:T]; mx = np.tile(tr.mx, (reps, 1))[:T]; my = np.tile(tr.my, (reps, 1))[:T]
+    ids = np.tile(tr.ids, (reps, 1))[:T]
+    out = []
+    for mode in (1, 5):
+        f, bt = make(hip, n, 0, mode, lm)
+        bt.load_trace(tw, mx, my, ids, bcast=True)
+        bt.profile(True)
+        bt.run(0, T)
+        _, launches = bt.profile_read(hip.K_TICK_CHAIN)
+        bt.profile(False)
+        out.append((f.state.copy(), f.cov.copy(), f.seen, launches, bt.status()))
+    assert out[0][3] == 2 and out[1][3] == T
+    assert out[0][4] == out[1][4]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
