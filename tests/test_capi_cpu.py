@@ -73,3 +73,20 @@ def test_rccl_reduction_refuses_without_a_device():
     with pytest.raises(nh.NuslamError) as ei:
         nh.Comm(bytes(nh.COMM_ID_BYTES), 1, 0, 0)
     assert ei.value.code in (nh.E_NODEV, nh.E_COMM)
+
+
+def test_generated_strip_blocks_are_in_step_with_their_generator(tmp_path):
+    """csrc/ekf_strips_blocks.inc (the inline-asm coefficient blocks of k_tick_strips_lane) is what tools/gen_strips_asm.py writes."""
+    import importlib.util, os, shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "shermbot-navigation_amd", "csrc", "ekf_strips_blocks.inc")
+    committed = open(inc).read()
+    # run the generator on a copy of the tree layout it expects
+    work = tmp_path / "w"
+    (work / "tools").mkdir(parents=True)
+    (work / "shermbot-navigation_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(os.path.join(root, "tools", "gen_strips_asm.py"), work / "tools" / "gen_strips_asm.py")
+    spec = importlib.util.spec_from_file_location("gen_strips_asm_copy", str(work / "tools" / "gen_strips_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert open(work / "shermbot-navigation_amd" / "csrc" / "ekf_strips_blocks.inc").read() == committed
